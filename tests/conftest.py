@@ -1,0 +1,23 @@
+"""Test configuration: registers the ``gpu`` marker and puts the product package directory
+(``opensearch-neural-pre-train_amd/`` -- holds ``snx`` and the ``src`` mirror of the reference
+interface) and the repo root (``oracle``) on sys.path."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "opensearch-neural-pre-train_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

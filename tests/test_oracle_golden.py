@@ -1,0 +1,229 @@
+"""Pins the CPU oracle (oracle/splade_oracle.py) against golden vectors captured from the
+reference code itself (tools/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import splade_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _npz(name):
+    return np.load(os.path.join(G, name))
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _g1():
+    z = _npz("g1_tiny_fwd_bwd.npz")
+    meta = json.load(open(os.path.join(G, "g1_tiny_fwd_bwd.json")))
+    params = {k[3:]: _t(z[k]) for k in z.files if k.startswith("w::")}
+    batch = {k[4:]: _t(z[k]) for k in z.files if k.startswith("in::")}
+    batch["num_negatives"] = meta["num_negatives"]
+    return z, meta, params, batch
+
+
+def test_g1_forward_matches_reference():
+    z, meta, params, b = _g1()
+    cfg = O.EncoderConfig.tiny()
+    for tag, pre in (("q", "query"), ("p", "positive"), ("n", "negative")):
+        sr, tw = O.splade_forward(params, cfg, b[pre + "_input_ids"], b[pre + "_attention_mask"])
+        np.testing.assert_allclose(sr.numpy(), z["out::" + tag], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(tw.numpy(), z["out::" + tag + "t"], atol=2e-6, rtol=0)
+        # top-k indices bit-exact (entries whose gap to the next rank exceeds the value error)
+        ref = _t(z["out::" + tag])
+        tv, ti = torch.topk(ref, 20, dim=-1)
+        ov, oi = torch.topk(sr, 20, dim=-1)
+        gap = (tv[:, :-1] - tv[:, 1:]) > 1e-5
+        ok = gap[:, 1:] & gap[:, :-1]
+        assert torch.equal(ti[:, 1:-1][ok], oi[:, 1:-1][ok])
+
+
+def test_g1_padded_rows_are_exact_zero_and_finite():
+    z, meta, params, b = _g1()
+    cfg = O.EncoderConfig.tiny()
+    sr, tw = O.splade_forward(params, cfg, b["negative_input_ids"], b["negative_attention_mask"])
+    assert torch.isfinite(sr).all() and torch.isfinite(tw).all()
+    assert (tw[b["negative_attention_mask"] == 0] == 0).all()
+
+
+def test_g1_loss_and_grads_match_reference():
+    z, meta, params, b = _g1()
+    cfg = O.EncoderConfig.tiny()
+    lc = O.LossConfig(**meta["loss_kwargs"])
+    leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    q, _ = O.splade_forward(leaves, cfg, b["query_input_ids"], b["query_attention_mask"])
+    p, _ = O.splade_forward(leaves, cfg, b["positive_input_ids"], b["positive_attention_mask"])
+    n, _ = O.splade_forward(leaves, cfg, b["negative_input_ids"], b["negative_attention_mask"])
+    n3 = n.view(q.shape[0], meta["num_negatives"], -1)
+    for t in (q, p, n):
+        t.retain_grad()
+    loss, d = O.loss_v33(lc, q, p, n3, meta["global_step"], b["teacher_pos_scores"], b["teacher_neg_scores"])
+    assert abs(loss.item() - float(z["out::loss"])) <= 1e-5 * max(1.0, abs(float(z["out::loss"])))
+    for k, v in meta["loss_dict"].items():
+        assert d[k] == pytest.approx(v, rel=2e-5, abs=1e-6), k
+    loss.backward()
+    np.testing.assert_allclose(q.grad.numpy(), z["out::dq"], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(p.grad.numpy(), z["out::dp"], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(n.grad.numpy(), z["out::dn"], atol=1e-6, rtol=1e-4)
+    for name, leaf in leaves.items():
+        ref = z["g::" + name]
+        got = leaf.grad.numpy()
+        denom = max(np.abs(ref).max(), 1e-8)
+        assert np.abs(got - ref).max() / denom < 2e-4, name
+
+
+def test_g4_loss_vectors():
+    z = _npz("g4_loss_vectors.npz")
+    cases = json.load(open(os.path.join(G, "g4_loss_vectors.json")))
+    assert len(cases) == 24
+    for c in cases:
+        pre = f"c{c['id']}::"
+        a, p, n = (_t(z[pre + x]).clone().requires_grad_(True) for x in "apn")
+        lc = O.LossConfig(**c["loss_kwargs"])
+        loss, d = O.loss_v33(lc, a, p, n, c["step"], _t(z[pre + "tp"]), _t(z[pre + "tn"]))
+        assert loss.item() == pytest.approx(c["loss"], rel=1e-5)
+        for k, v in c["loss_dict"].items():
+            assert d[k] == pytest.approx(v, rel=1e-5, abs=1e-7), (c["id"], k)
+        loss.backward()
+        for x, t in zip("apn", (a, p, n)):
+            np.testing.assert_allclose(t.grad.numpy(), z[pre + "d" + x], atol=1e-7, rtol=2e-4)
+
+
+@pytest.mark.parametrize("tag", ["w1", "w2"])
+def test_g2_train_epoch_matches_reference(tag):
+    """The reference's own train_epoch (tiny config, 8 micro-steps, accum 4 -> 2 optimizer
+    steps; w2 = two gloo DDP ranks) vs the oracle's restated loop."""
+    z = _npz(f"g2_train_epoch_{tag}.npz")
+    meta = json.load(open(os.path.join(G, f"g2_train_epoch_{tag}.json")))
+    conf = meta["conf"]
+    world = conf["world"]
+    cfg = O.EncoderConfig.tiny()
+    params = O.perturb_params(O.init_params(cfg, seed=42), seed=7, scale=3.0)
+    nb = meta["n_batches"]
+    batches = []
+    for i in range(nb):
+        b = {k.split("::")[1]: _t(z[k]) for k in z.files if k.startswith(f"b{i}::")}
+        b["num_negatives"] = 1
+        batches.append(b)
+    lc = O.LossConfig(lambda_q=conf["lambda_q"], lambda_d=conf["lambda_d"],
+                      flops_warmup_steps=conf["flops_warmup_steps"],
+                      lambda_initial_ratio=conf["lambda_initial_ratio"])
+    # DistributedSampler(shuffle=False) deals batch i to rank i % world; DDP averages the
+    # per-rank gradients on every micro-step.  Emulate: rank r's micro-step j uses batch j*world+r.
+    states = [O.TrainState({n: p.clone() for n, p in params.items()}) for _ in range(world)]
+    per_rank = [[batches[j * world + r] for j in range(nb // world)] for r in range(world)]
+    losses0 = []
+    gs = 0
+    accs = [dict() for _ in range(world)]
+    for j in range(nb // world):
+        grads_r = []
+        for r in range(world):
+            st = states[r]
+            leaves = {n: p.detach().clone().requires_grad_(True) for n, p in st.params.items()}
+            b = per_rank[r][j]
+            q, _ = O.splade_forward(leaves, cfg, b["query_input_ids"], b["query_attention_mask"])
+            p_, _ = O.splade_forward(leaves, cfg, b["positive_input_ids"], b["positive_attention_mask"])
+            n_, _ = O.splade_forward(leaves, cfg, b["negative_input_ids"], b["negative_attention_mask"])
+            loss, d = O.loss_v33(lc, q, p_, n_, gs)
+            (loss / conf["accum"]).backward()
+            grads_r.append({n: l.grad for n, l in leaves.items()})
+            if r == 0:
+                losses0.append(loss.item())
+        avg = {n: sum(g[n] for g in grads_r) / world for n in grads_r[0]}
+        for r in range(world):
+            for n, g in avg.items():
+                accs[r][n] = g if n not in accs[r] else accs[r][n] + g
+        if (j + 1) % conf["accum"] == 0:
+            lr = conf["lr"] * O.cosine_lr_factor(gs, conf["warmup"], conf["total_steps"])
+            for r in range(world):
+                O.adamw_step(states[r], accs[r], lr, conf["wd"], conf["clip"])
+                accs[r] = {}
+            gs += 1
+    assert gs == meta["global_step"] == 2
+    np.testing.assert_allclose(np.array(losses0), z["losses"], rtol=2e-4)
+    for n, p in states[0].params.items():
+        ref = z["p::" + n]
+        assert np.abs(p.numpy() - ref).max() < 5e-5, n
+        # the update must actually have moved the weights (lr=5e-3)
+    moved = np.abs(states[0].params["model.head.dense.weight"].numpy() - params["model.head.dense.weight"].numpy()).max()
+    assert moved > 1e-3
+
+
+def test_g5_collator_layout(golden_dir):
+    from src.train.data.dataloader import TripletCollator
+    from tests.helpers import StubTokenizer
+    fx = json.load(open(os.path.join(golden_dir, "g5_collator.json")))
+    col = TripletCollator(tokenizer=StubTokenizer(), **fx["collator_kwargs"])
+    import copy
+    for tag in ("single", "multi"):
+        out = col(copy.deepcopy(fx[tag]["items"]))
+        exp = fx[tag]["out"]
+        assert set(out.keys()) == set(exp.keys())
+        for k, v in exp.items():
+            got = out[k].tolist() if torch.is_tensor(out[k]) else out[k]
+            if isinstance(v, list) and v and isinstance(v[0], (float, list)) and k.startswith("teacher"):
+                np.testing.assert_allclose(np.array(got), np.array(v), rtol=1e-6)
+            else:
+                assert got == v, (tag, k)
+
+
+@pytest.fixture(scope="module")
+def full_params():
+    cfg = O.EncoderConfig()
+    return cfg, O.perturb_params(O.init_params(cfg, seed=42), seed=7, bias_mean=-0.2)
+
+
+def test_g3_full_size_matches_reference(full_params):
+    """149M-parameter config, B=4, q64/d256 ragged: sparse vectors, top-k, loss terms, gradient
+    norms of all 137 tensors and gradient probes vs the reference (fp32 CPU path)."""
+    import hashlib
+    cfg, params = full_params
+    z = _npz("g3_full_fwd_bwd.npz")
+    meta = json.load(open(os.path.join(G, "g3_full_fwd_bwd.json")))
+    for k, h in meta["weight_sha256"].items():
+        assert hashlib.sha256(params[k].contiguous().numpy().tobytes()).hexdigest() == h, k
+    b = {k[4:]: _t(z[k]) for k in z.files if k.startswith("in::")}
+    leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    reps = {}
+    for tag, pre in (("q", "query"), ("p", "positive"), ("n", "negative")):
+        sr, tw = O.splade_forward(leaves, cfg, b[pre + "_input_ids"], b[pre + "_attention_mask"])
+        sr.retain_grad()
+        reps[tag] = sr
+        srd = sr.detach()
+        np.testing.assert_allclose(tw.detach().numpy(), z[f"out::{tag}_tw"], atol=5e-6, rtol=0)
+        np.testing.assert_allclose(srd.double().sum(-1).numpy(), z[f"out::{tag}_sum"], rtol=1e-5)
+        np.testing.assert_allclose((srd.double() ** 2).sum(-1).numpy(), z[f"out::{tag}_sq"], rtol=1e-5)
+        tv, ti = torch.topk(srd, 256, dim=-1)
+        np.testing.assert_allclose(tv.numpy(), z[f"out::{tag}_topv"], atol=5e-6, rtol=0)
+        rv, ri = _t(z[f"out::{tag}_topv"]), _t(z[f"out::{tag}_topi"])
+        gap = (rv[:, :-1] - rv[:, 1:]) > 2e-5
+        ok = gap[:, 1:] & gap[:, :-1]              # rank i is unambiguous if both neighbours are far
+        assert torch.equal(ri[:, 1:-1][ok], ti[:, 1:-1][ok])
+        assert ok.float().mean() > 0.8
+    lc = O.LossConfig(**meta["loss_kwargs"])
+    loss, d = O.loss_v33(lc, reps["q"], reps["p"], reps["n"], meta["global_step"])
+    assert loss.item() == pytest.approx(meta["loss"], rel=2e-5)
+    for k, v in meta["loss_dict"].items():
+        assert d[k] == pytest.approx(v, rel=5e-5, abs=1e-6), k
+    loss.backward()
+    for tag in "qpn":
+        np.testing.assert_allclose(reps[tag].grad.double().sum(-1).numpy(), z[f"out::d{tag}_sum"], rtol=1e-4, atol=1e-6)
+    norms = dict(zip(meta["grad_names"], meta["grad_norms"]))
+    for n, leaf in leaves.items():
+        assert float(leaf.grad.double().norm()) == pytest.approx(norms[n], rel=2e-3), n
+    for k in z.files:
+        if not k.startswith("gprobe::model"):
+            continue
+        g = leaves[k[8:]].grad
+        got = (g[:8, :64] if g.dim() == 2 else g[:512]).numpy()
+        ref = z[k]
+        assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-12), k
+    e = leaves["model.model.embeddings.tok_embeddings.weight"].grad
+    np.testing.assert_allclose(e.double().norm(dim=1).float().numpy(), z["gprobe::emb_rownorm"], rtol=5e-3, atol=1e-7)
