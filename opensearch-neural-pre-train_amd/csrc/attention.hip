@@ -1,0 +1,181 @@
+// Bidirectional attention for ModernBERT (K5g global / K5l sliding-window):
+// softmax(q k^T / sqrt(64) + mask) v with key-padding mask and, on local layers, the inclusive
+// band |i - j| <= window.  Replaces torch SDPA as called from transformers
+// modeling_modernbert.py:286-297 (masks: masking_utils.py:141-150).
+//
+// Layout: qkv [T, 3, heads, 64] bf16 (RoPE already applied to q,k), sequences are row ranges
+// cu_seqlens[s] .. cu_seqlens[s+1]; out [T, heads*64] bf16; lse [heads, T] fp32.
+//
+// Kernel shape (CDNA4): one workgroup = 4 waves = 64 query rows of one (sequence, head); K/V
+// stream through LDS in 64-key tiles.  The score tile is computed TRANSPOSED (S^T = K Q^T) so
+// each lane owns one query column: the online-softmax statistics are lane-local plus two
+// xor-shuffles, and the fp32 score accumulators, converted to bf16, ARE the B operand of the
+// second product O^T = V^T P^T (no LDS round trip for P).  V^T fragments come from the
+// row-major V tile with ds_read_b64_tr_b16 (hardware transpose).  The contraction index of the
+// second product is a permutation of the key index (lane group g, element j <-> key
+// 16*(2c + j/4) + 4g + j%4); both operands use the same permutation.
+#include "common.h"
+#include "snx.h"
+
+#define NEG_BIG (-1.0e30f)
+
+__device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
+
+__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+}
+
+// Stage one 64-row x 64-dim bf16 tile (rows key0.. of the K or V third) into LDS, swizzled.
+template <bool IS_V>
+__device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ base, long row_stride, int key0, int slen,
+                                         char* lds) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = threadIdx.x + i * 256;
+    const int r = id >> 3, c = id & 7;
+    int key = key0 + r;
+    key = key < slen ? key : slen - 1;
+    const bf16x8 v = *(const bf16x8*)(base + (long)key * row_stride + c * 8);
+    *(bf16x8*)(lds + (IS_V ? v_off(r, c) : k_off(r, c))) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
+                                                       const int32_t* __restrict__ cu_seqlens,
+                                                       const int64_t* __restrict__ mask, bf16_t* __restrict__ out,
+                                                       float* __restrict__ lse, int T, int heads, int window,
+                                                       float scale) {
+  __shared__ __attribute__((aligned(16))) char sK[64 * 128];
+  __shared__ __attribute__((aligned(16))) char sV[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char sValid[64];
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= slen) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const long rs = 3L * heads * 64;                  // token stride in qkv
+  const int H = heads * 64;
+  const bf16_t* qbase = qkv + (long)s0 * rs + head * 64;
+  const bf16_t* kbase = qbase + H;
+  const bf16_t* vbase = qbase + 2 * H;
+
+  const int qpos = q0 + wave * 16 + li;             // this lane's query row (within the sequence)
+  const int qrow = qpos < slen ? qpos : slen - 1;
+  bf16x8 qf[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) qf[c] = *(const bf16x8*)(qbase + (long)qrow * rs + c * 32 + g * 8);
+
+  int j_lo = 0, j_hi = (slen - 1) >> 6;
+  if (window >= 0) {
+    const int lo = q0 - window, hi = q0 + 63 + window;
+    j_lo = lo > 0 ? (lo >> 6) : 0;
+    const int jh = (hi < slen - 1 ? hi : slen - 1) >> 6;
+    j_hi = jh;
+  }
+
+  f32x4 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  for (int j = j_lo; j <= j_hi; ++j) {
+    const int key0 = j * 64;
+    __syncthreads();                                 // previous tile fully consumed
+    stage_kv<false>(kbase, rs, key0, slen, sK);
+    stage_kv<true>(vbase, rs, key0, slen, sV);
+    if (threadIdx.x < 64) {
+      const int key = key0 + threadIdx.x;
+      sValid[threadIdx.x] = (key < slen && mask[s0 + key] != 0) ? 1 : 0;
+    }
+    __syncthreads();
+
+    // S^T tile: 64 keys x 16 queries per wave
+    f32x4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bf16x8 kf = *(const bf16x8*)(sK + k_off(kt * 16 + li, 4 * c + g));
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[c], s[kt], 0, 0, 0);
+      }
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const uint32_t vm = *(const uint32_t*)(sValid + kt * 16 + g * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + kt * 16 + g * 4 + r;
+        bool ok = (vm >> (8 * r)) & 1;
+        if (window >= 0) {
+          const int dlt = qpos - key;
+          ok = ok && (dlt <= window) && (dlt >= -window);
+        }
+        const float v = ok ? s[kt][r] * scale : NEG_BIG;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float rsum = 0.f;
+    bf16x8 pb[2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[kt][r] - m_new);
+        rsum += p;
+        pb[kt >> 1][(kt & 1) * 4 + r] = f2bf(p);
+      }
+    rsum += __shfl_xor(rsum, 16, 64);
+    rsum += __shfl_xor(rsum, 32, 64);
+    l_run = l_run * alpha + rsum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] *= alpha;
+
+    // O^T += V^T P^T
+    const int tq = li >> 2, tp = li & 3;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int r0 = 16 * (2 * c) + 4 * g + tq, r1 = r0 + 16;
+        const int chunk = 2 * d + (tp >> 1);
+        const bf16x4 a0 = lds_tr16(sV + v_off(r0, chunk) + (tp & 1) * 8);
+        const bf16x4 a1 = lds_tr16(sV + v_off(r1, chunk) + (tp & 1) * 8);
+        const bf16x8 vf = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[c], o[d], 0, 0, 0);
+      }
+    }
+  }
+
+  if (qpos < slen) {
+    const float inv = 1.0f / l_run;
+    bf16_t* orow = out + (long)(s0 + qpos) * H + head * 64 + g * 4;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      bf16x4 v = {f2bf(o[d][0] * inv), f2bf(o[d][1] * inv), f2bf(o[d][2] * inv), f2bf(o[d][3] * inv)};
+      *(bf16x4*)(orow + d * 16) = v;
+    }
+    if (g == 0) lse[(long)head * T + s0 + qpos] = m_run + __logf(l_run);
+  }
+}
+
+extern "C" int snx_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse,
+                            int32_t T, int32_t nseq, int32_t max_seqlen, int32_t heads, int32_t head_dim,
+                            int32_t window, hipStream_t st) {
+  if (!qkv || !cu_seqlens || !mask || !out || !lse || T <= 0 || nseq <= 0 || max_seqlen <= 0) return SNX_E_ARG;
+  if (head_dim != 64 || heads <= 0) return SNX_E_SHAPE;
+  dim3 grid(cdiv(max_seqlen, 64), heads, nseq);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, cu_seqlens, mask, (bf16_t*)out,
+                     lse, T, heads, window, 0.125f);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}

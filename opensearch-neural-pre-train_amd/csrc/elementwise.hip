@@ -1,0 +1,434 @@
+// HBM-bound token-wise kernels of the encoder (K1, K2, K4, GeGLU of K7, GELU+LN of K9 and their
+// backward passes).  One wave per token row, 16-byte vector accesses, all math
+// in fp32 with the reference's autocast cast points (fp32 residual stream / LayerNorm / RoPE,
+// bf16 GELU and GeGLU product).  References: transformers modeling_modernbert.py:64-71
+// (embeddings), :89-91 (GeGLU), :196-219 (RoPE), :312-314,420,487 (LayerNorm), :489-490 (head).
+#include "common.h"
+#include "snx.h"
+
+#define ROWS_PER_BLOCK 4   // 256 threads = 4 waves = 4 token rows
+
+// ------------------------------------------------------------------------------------------
+// weight cache: fp32 master -> bf16 (and bf16 transposed for the dX GEMMs)
+// ------------------------------------------------------------------------------------------
+__global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    const f32x4 v = *(const f32x4*)(in + i);
+    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    *(bf16x4*)(out + i) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long j = n & ~3L; j < n; ++j) out[j] = f2bf(in[j]);
+}
+
+// in [R, C] fp32 row-major -> out [C, R] bf16 row-major (64x64 tiles through LDS)
+__global__ void cast_transpose_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int R, int C) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 4 rows per pass
+  for (int r = ty; r < 64; r += 4) {
+    const int gr = r0 + r, gc = c0 + tx;
+    tile[r][tx] = (gr < R && gc < C) ? in[(long)gr * C + gc] : 0.f;
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int gc = c0 + c, gr = r0 + tx;
+    if (gc < C && gr < R) out[(long)gc * R + gr] = f2bf(tile[tx][c]);
+  }
+}
+
+extern "C" int snx_cast_bf16(const float* in, void* out, int64_t n, hipStream_t st) {
+  if (!in || !out || n <= 0) return SNX_E_ARG;
+  if (((uintptr_t)in & 15) || ((uintptr_t)out & 7)) return SNX_E_ARG;
+  int blocks = cdiv(n, 256 * 4);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, st, in, (bf16_t*)out, (long)n);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+extern "C" int snx_cast_transpose_bf16(const float* in, void* out, int32_t R, int32_t C, hipStream_t st) {
+  if (!in || !out || R <= 0 || C <= 0) return SNX_E_ARG;
+  hipLaunchKernelGGL(cast_transpose_bf16_kernel, dim3(cdiv(C, 64), cdiv(R, 64)), dim3(256), 0, st, in,
+                     (bf16_t*)out, R, C);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm (no bias), one wave per row; NV = H / 256 float4 per lane
+// ------------------------------------------------------------------------------------------
+template <int NV>
+struct RowVec {
+  f32x4 v[NV];
+  __device__ __forceinline__ void load_f32(const float* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *(const f32x4*)(p + (i * 64 + lane) * 4);
+  }
+  __device__ __forceinline__ void load_bf16(const bf16_t* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bf16x4 b = *(const bf16x4*)(p + (i * 64 + lane) * 4);
+      v[i] = (f32x4){bf2f(b[0]), bf2f(b[1]), bf2f(b[2]), bf2f(b[3])};
+    }
+  }
+  __device__ __forceinline__ void store_f32(float* p, int lane) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *(f32x4*)(p + (i * 64 + lane) * 4) = v[i];
+  }
+  __device__ __forceinline__ void store_bf16(bf16_t* p, int lane) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      bf16x4 b = {f2bf(v[i][0]), f2bf(v[i][1]), f2bf(v[i][2]), f2bf(v[i][3])};
+      *(bf16x4*)(p + (i * 64 + lane) * 4) = b;
+    }
+  }
+  __device__ __forceinline__ float sum() const {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    return wave_sum(s);
+  }
+};
+
+// normalise in place: x <- (x - mean) * rstd ; returns rstd
+template <int NV>
+__device__ __forceinline__ float ln_normalize(RowVec<NV>& x, int H, float eps) {
+  const float mean = x.sum() / (float)H;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x.v[i][e] -= mean;
+      s += x.v[i][e] * x.v[i][e];
+    }
+  const float var = wave_sum(s) / (float)H;
+  const float rstd = rsqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) x.v[i] *= rstd;
+  return rstd;
+}
+
+// MODE 0: src = h fp32 rows.  MODE 1: src = E[ids[t]] (embedding gather), also writes h fp32.
+// MODE 2: src = gelu(bf16 d) evaluated on the bf16 tensor (head: LN(gelu(dense))).
+template <int NV, int MODE>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h, const int64_t* __restrict__ ids,
+                                                     const float* __restrict__ E, const bf16_t* __restrict__ d,
+                                                     const float* __restrict__ w, float* __restrict__ h_out,
+                                                     bf16_t* __restrict__ x_out, bf16_t* __restrict__ x0_out,
+                                                     int T, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (t >= T) return;
+  RowVec<NV> x, wv;
+  if (MODE == 0) {
+    x.load_f32(h + (long)t * H, lane);
+  } else if (MODE == 1) {
+    x.load_f32(E + ids[t] * (long)H, lane);
+  } else {
+    x.load_bf16(d + (long)t * H, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x.v[i][e] = rbf(gelu_f(x.v[i][e]));
+  }
+  wv.load_f32(w, lane);
+  ln_normalize<NV>(x, H, eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) x.v[i] *= wv.v[i];
+  if (MODE == 1) {
+    x.store_f32(h_out + (long)t * H, lane);      // residual stream starts here (fp32)
+    x.store_bf16(x0_out + (long)t * H, lane);    // layer 0 has no attn_norm: Wqkv reads bf16(h)
+  } else {
+    x.store_bf16(x_out + (long)t * H, lane);
+  }
+}
+
+#define DISPATCH_NV(H, CALL)                 \
+  switch ((H) / 256) {                       \
+    case 1: { constexpr int NV = 1; CALL; } break; \
+    case 2: { constexpr int NV = 2; CALL; } break; \
+    case 3: { constexpr int NV = 3; CALL; } break; \
+    case 4: { constexpr int NV = 4; CALL; } break; \
+    default: return SNX_E_SHAPE;             \
+  }
+
+static inline bool bad_h(int H) { return H <= 0 || (H % 256) != 0 || H > 1024; }
+
+extern "C" int snx_ln_fwd(const float* h, const float* w, void* x_out, int32_t T, int32_t H, float eps,
+                          hipStream_t st) {
+  if (!h || !w || !x_out || T <= 0) return SNX_E_ARG;
+  if (bad_h(H)) return SNX_E_SHAPE;
+  DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<NV, 0>), dim3(cdiv(T, ROWS_PER_BLOCK)), dim3(256), 0, st, h,
+                                    nullptr, nullptr, nullptr, w, nullptr, (bf16_t*)x_out, nullptr, T, H, eps));
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+extern "C" int snx_embed_ln_fwd(const int64_t* ids, const float* E, const float* w, float* h_out, void* x0_out,
+                                int32_t T, int32_t H, float eps, hipStream_t st) {
+  if (!ids || !E || !w || !h_out || !x0_out || T <= 0) return SNX_E_ARG;
+  if (bad_h(H)) return SNX_E_SHAPE;
+  DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<NV, 1>), dim3(cdiv(T, ROWS_PER_BLOCK)), dim3(256), 0, st,
+                                    nullptr, ids, E, nullptr, w, h_out, nullptr, (bf16_t*)x0_out, T, H, eps));
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+extern "C" int snx_gelu_ln_fwd(const void* d, const float* w, void* x_out, int32_t T, int32_t H, float eps,
+                               hipStream_t st) {
+  if (!d || !w || !x_out || T <= 0) return SNX_E_ARG;
+  if (bad_h(H)) return SNX_E_SHAPE;
+  DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<NV, 2>), dim3(cdiv(T, ROWS_PER_BLOCK)), dim3(256), 0, st,
+                                    nullptr, nullptr, nullptr, (const bf16_t*)d, w, nullptr, (bf16_t*)x_out,
+                                    nullptr, T, H, eps));
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm backward.  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w,
+// dw[j] += sum_t dy[t,j] * xhat[t,j].  Each block walks `rows_per_block` rows with its 4 waves,
+// accumulating dw in registers (a lane owns the same columns for every row), reduces the 4
+// waves through LDS and issues one float atomic per column per block.
+//   MODE 0: input h fp32;   dh[t] += dx                       (residual-stream LN)
+//   MODE 1: input E[ids[t]]; gradE[ids[t]] += dx (atomics, skip pad id)   (embedding LN)
+//   MODE 2: input gelu(bf16 d); dd[t] = bf16(bf16(dx) * gelu'(d))          (head LN)
+//   MODE 3: input h fp32;   dh[t]  = dx  (overwrite: the final_norm, first op of backward)
+// ------------------------------------------------------------------------------------------
+template <int NV, int MODE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ dyf,
+                                                     const float* __restrict__ h, const int64_t* __restrict__ ids,
+                                                     const float* __restrict__ E, const bf16_t* __restrict__ d,
+                                                     const float* __restrict__ w, float* __restrict__ dh,
+                                                     float* __restrict__ gradE, bf16_t* __restrict__ dd,
+                                                     float* __restrict__ dw, int T, int H, float eps,
+                                                     int rows_per_block, int pad_id) {
+  __shared__ float red[ROWS_PER_BLOCK][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  RowVec<NV> wv, dwacc;
+  wv.load_f32(w, lane);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) dwacc.v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int t_begin = blockIdx.x * rows_per_block;
+  const int t_end = min(T, t_begin + rows_per_block);
+  for (int t = t_begin + wave; t < t_end; t += ROWS_PER_BLOCK) {
+    RowVec<NV> x, g, raw;
+    long id = 0;
+    if (MODE == 0 || MODE == 3) {
+      x.load_f32(h + (long)t * H, lane);
+    } else if (MODE == 1) {
+      id = ids[t];
+      x.load_f32(E + id * (long)H, lane);
+    } else {
+      raw.load_bf16(d + (long)t * H, lane);
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x.v[i][e] = rbf(gelu_f(raw.v[i][e]));
+    }
+    const float rstd = ln_normalize<NV>(x, H, eps);     // x = xhat
+    if (MODE == 1) g.load_f32(dyf + (long)t * H, lane); // grad wrt embeddings output is the fp32 dh stream
+    else g.load_bf16(dy + (long)t * H, lane);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dwacc.v[i][e] += g.v[i][e] * x.v[i][e];
+        g.v[i][e] *= wv.v[i][e];
+        s1 += g.v[i][e];
+        s2 += g.v[i][e] * x.v[i][e];
+      }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g.v[i][e] = rstd * (g.v[i][e] - s1 - x.v[i][e] * s2);   // g = dx
+    if (MODE == 0) {
+      RowVec<NV> cur;
+      cur.load_f32(dh + (long)t * H, lane);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) cur.v[i] += g.v[i];
+      cur.store_f32(dh + (long)t * H, lane);
+    } else if (MODE == 3) {
+      g.store_f32(dh + (long)t * H, lane);
+    } else if (MODE == 1) {
+      if (id != pad_id) {                                  // nn.Embedding(padding_idx): no grad to the pad row
+        float* dst = gradE + id * (long)H;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(dst + (i * 64 + lane) * 4 + e, g.v[i][e]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g.v[i][e] = rbf(rbf(g.v[i][e]) * gelu_grad_f(raw.v[i][e]));
+      g.store_bf16(dd + (long)t * H, lane);
+    }
+  }
+  // reduce dw over the 4 waves, then one atomic per column
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][(i * 64 + lane) * 4 + e] = dwacc.v[i][e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    atomicAdd(dw + c, s);
+  }
+}
+
+static inline int ln_bwd_rows_per_block(int T) {
+  int rpb = cdiv(T, 1024);                 // ~1024 blocks: 4 per CU
+  rpb = ((rpb + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * ROWS_PER_BLOCK;
+  return rpb < ROWS_PER_BLOCK ? ROWS_PER_BLOCK : rpb;
+}
+
+extern "C" int snx_ln_bwd(const void* dy, const float* h, const float* w, float* dh, float* dw, int32_t T,
+                          int32_t H, float eps, int32_t overwrite, hipStream_t st) {
+  if (!dy || !h || !w || !dh || !dw || T <= 0) return SNX_E_ARG;
+  if (bad_h(H)) return SNX_E_SHAPE;
+  const int rpb = ln_bwd_rows_per_block(T);
+  if (overwrite) {
+    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 3>), dim3(cdiv(T, rpb)), dim3(256), 0, st,
+                                      (const bf16_t*)dy, nullptr, h, nullptr, nullptr, nullptr, w, dh, nullptr,
+                                      nullptr, dw, T, H, eps, rpb, -1));
+  } else {
+    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 0>), dim3(cdiv(T, rpb)), dim3(256), 0, st,
+                                      (const bf16_t*)dy, nullptr, h, nullptr, nullptr, nullptr, w, dh, nullptr,
+                                      nullptr, dw, T, H, eps, rpb, -1));
+  }
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+extern "C" int snx_embed_ln_bwd(const float* dh, const int64_t* ids, const float* E, const float* w, float* gradE,
+                                float* dw, int32_t T, int32_t H, float eps, int32_t pad_id, hipStream_t st) {
+  if (!dh || !ids || !E || !w || !gradE || !dw || T <= 0) return SNX_E_ARG;
+  if (bad_h(H)) return SNX_E_SHAPE;
+  const int rpb = ln_bwd_rows_per_block(T);
+  DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 1>), dim3(cdiv(T, rpb)), dim3(256), 0, st, nullptr, dh,
+                                    nullptr, ids, E, nullptr, w, nullptr, gradE, nullptr, dw, T, H, eps, rpb,
+                                    pad_id));
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+extern "C" int snx_gelu_ln_bwd(const void* dy, const void* d, const float* w, void* dd, float* dw, int32_t T,
+                               int32_t H, float eps, hipStream_t st) {
+  if (!dy || !d || !w || !dd || !dw || T <= 0) return SNX_E_ARG;
+  if (bad_h(H)) return SNX_E_SHAPE;
+  const int rpb = ln_bwd_rows_per_block(T);
+  DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 2>), dim3(cdiv(T, rpb)), dim3(256), 0, st,
+                                    (const bf16_t*)dy, nullptr, nullptr, nullptr, nullptr, (const bf16_t*)d, w,
+                                    nullptr, nullptr, (bf16_t*)dd, dw, T, H, eps, rpb, -1));
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// RoPE in place on the q and k thirds of qkv [T, 3, heads, 64] (half-split rotate_half).
+// tab = [max_pos][32] float2 (cos, sin) for this layer type.  inverse=1 applies the transposed
+// rotation (backward).  One thread = 8 dims of the low half + the matching 8 of the high half.
+// ------------------------------------------------------------------------------------------
+__global__ void rope_kernel(bf16_t* __restrict__ qkv, const f32x2* __restrict__ tab, const int32_t* __restrict__ pos,
+                            long n_items, int heads, int inverse) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;   // item = (t, which(q|k), head, quarter)
+  if (gid >= n_items) return;
+  const int quarter = gid & 3;
+  long rest = gid >> 2;
+  const int head = rest % heads; rest /= heads;
+  const int which = rest & 1;
+  const long t = rest >> 1;
+  bf16_t* base = qkv + (t * 3 + which) * (long)heads * 64 + head * 64 + quarter * 8;
+  const bf16x8 lo = *(const bf16x8*)base, hi = *(const bf16x8*)(base + 32);
+  const f32x2* cs = tab + (long)pos[t] * 32 + quarter * 8;
+  bf16x8 olo, ohi;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float c = cs[e][0], s = inverse ? -cs[e][1] : cs[e][1];
+    const float x1 = bf2f(lo[e]), x2 = bf2f(hi[e]);
+    olo[e] = f2bf(x1 * c - x2 * s);
+    ohi[e] = f2bf(x2 * c + x1 * s);
+  }
+  *(bf16x8*)base = olo;
+  *(bf16x8*)(base + 32) = ohi;
+}
+
+extern "C" int snx_rope_inplace(void* qkv, const float* cos_sin_tab, const int32_t* pos, int32_t T, int32_t heads,
+                                int32_t inverse, hipStream_t st) {
+  if (!qkv || !cos_sin_tab || !pos || T <= 0 || heads <= 0) return SNX_E_ARG;
+  const long n = (long)T * 2 * heads * 4;
+  hipLaunchKernelGGL(rope_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (bf16_t*)qkv, (const f32x2*)cos_sin_tab, pos,
+                     n, heads, inverse);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// GeGLU: u = [a | g] bf16 [T, 2I];  y = bf16( bf16(gelu(a)) * g )        (hf:90-91)
+// backward: dact = bf16(dy*g), dg = bf16(dy*act), da = bf16(dact * gelu'(a))
+// ------------------------------------------------------------------------------------------
+__global__ void geglu_fwd_kernel(const bf16_t* __restrict__ u, bf16_t* __restrict__ y, long n8, int I8) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n8) return;
+  const long t = gid / I8;
+  const int c = gid % I8;
+  const bf16x8 a = *(const bf16x8*)(u + t * (long)I8 * 16 + c * 8);
+  const bf16x8 g = *(const bf16x8*)(u + t * (long)I8 * 16 + (long)I8 * 8 + c * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(rbf(gelu_f(bf2f(a[e]))) * bf2f(g[e]));
+  *(bf16x8*)(y + gid * 8) = o;
+}
+
+__global__ void geglu_bwd_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ dy, bf16_t* __restrict__ du,
+                                 long n8, int I8) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n8) return;
+  const long t = gid / I8;
+  const int c = gid % I8;
+  const long oa = t * (long)I8 * 16 + c * 8, og = oa + (long)I8 * 8;
+  const bf16x8 a = *(const bf16x8*)(u + oa), g = *(const bf16x8*)(u + og), d = *(const bf16x8*)(dy + gid * 8);
+  bf16x8 da, dg;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float af = bf2f(a[e]), gf = bf2f(g[e]), df = bf2f(d[e]);
+    const float act = rbf(gelu_f(af));
+    dg[e] = f2bf(df * act);
+    da[e] = f2bf(rbf(df * gf) * gelu_grad_f(af));
+  }
+  *(bf16x8*)(du + oa) = da;
+  *(bf16x8*)(du + og) = dg;
+}
+
+extern "C" int snx_geglu_fwd(const void* u, void* y, int32_t T, int32_t I, hipStream_t st) {
+  if (!u || !y || T <= 0 || I <= 0) return SNX_E_ARG;
+  if (I % 8) return SNX_E_SHAPE;
+  const long n8 = (long)T * (I / 8);
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(cdiv(n8, 256)), dim3(256), 0, st, (const bf16_t*)u, (bf16_t*)y, n8, I / 8);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+extern "C" int snx_geglu_bwd(const void* u, const void* dy, void* du, int32_t T, int32_t I, hipStream_t st) {
+  if (!u || !dy || !du || T <= 0 || I <= 0) return SNX_E_ARG;
+  if (I % 8) return SNX_E_SHAPE;
+  const long n8 = (long)T * (I / 8);
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(cdiv(n8, 256)), dim3(256), 0, st, (const bf16_t*)u, (const bf16_t*)dy,
+                     (bf16_t*)du, n8, I / 8);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+// dh fp32 -> bf16 (grad of a bf16 branch output taken from the fp32 residual-gradient stream)
+extern "C" int snx_cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t st) {
+  return snx_cast_bf16(in, out, n, st);
+}

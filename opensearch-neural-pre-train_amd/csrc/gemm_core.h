@@ -1,0 +1,106 @@
+// bf16 MFMA GEMM main loop for C[M,N] = A[M,K] * B[N,K]^T  (both operands K-contiguous: the
+// "NT" form every Linear of the encoder reduces to; weights are stored [out,in]).
+//
+// Design (CDNA4): BMxBNx64 tile, WAVES_M x WAVES_N waves of 64 lanes, each wave owns a
+// (BM/WAVES_M)x(BN/WAVES_N) sub-tile as MI x NI accumulators of v_mfma_f32_16x16x32_bf16.
+// Operand tiles go HBM/L2 -> LDS with LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+// instruction, no VGPR round trip), double buffered: the DMA of K-tile t+1 is in flight while
+// tile t is multiplied.  LDS rows are 128 B (64 bf16 of K); the eight 16-B chunks of a row are
+// XOR-swizzled with (row & 7) so that the ds_read_b128 fragment reads (16 rows x one chunk per
+// lane group) are bank-conflict free.  LDS-DMA writes lane-linear, so the swizzle is applied
+// to the per-lane SOURCE address and again on the read (same involution).
+#pragma once
+#include "common.h"
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct GemmCore {
+  static constexpr int BK = 64;
+  static constexpr int NW = WAVES_M * WAVES_N;
+  static constexpr int NTHREADS = NW * 64;
+  static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  static constexpr int MI = WTM / 16, NI = WTN / 16;
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over waves");
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of 16");
+
+  // Stage ROWS x 64 bf16 (rows row0.. of a K-contiguous matrix with leading dim ld, K offset k0)
+  // into lds.  Rows past row_max-1 are clamped (re-read of a valid row; results discarded by
+  // the caller's epilogue guard).
+  template <int ROWS>
+  static __device__ __forceinline__ void stage(const bf16_t* __restrict__ g, long ld, int row0, int row_max,
+                                               int k0, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 8 / NW; ++i) {
+      const int ci = i * NW + wave;               // 8-row group written by this wave instruction
+      const int r = ci * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (r & 7);         // logical 16-B chunk held at physical slot lane&7
+      int gr = row0 + r;
+      gr = gr < row_max ? gr : row_max - 1;
+      const bf16_t* src = g + (long)gr * ld + k0 + c * 8;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + ci * 1024), 16, 0, 0);
+    }
+  }
+
+  static __device__ __forceinline__ bf16x8 frag(const char* tile, int row, int chunk) {
+    return *(const bf16x8*)(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+  }
+
+  // acc must be zero-initialised (or hold the running sum) by the caller.
+  static __device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, long lda, int m0, int M,
+                                                  const bf16_t* __restrict__ B, long ldb, int n0, int N,
+                                                  int K, char* smem, f32x4 (&acc)[MI][NI]) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int nk = K / BK;
+    stage<BM>(A, lda, m0, M, 0, smem, wave, lane);
+    stage<BN>(B, ldb, n0, N, 0, smem + A_BYTES, wave, lane);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                               // tile kt landed; everyone left tile kt-1
+      char* cur = smem + (kt & 1) * STAGE_BYTES;
+      if (kt + 1 < nk) {
+        char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+        stage<BM>(A, lda, m0, M, (kt + 1) * BK, nxt, wave, lane);
+        stage<BN>(B, ldb, n0, N, (kt + 1) * BK, nxt + A_BYTES, wave, lane);
+      }
+      const char* ta = cur;
+      const char* tb = cur + A_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 a[MI], b[NI];
+        const int chunk = kk * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = frag(ta, wm * WTM + i * 16 + (lane & 15), chunk);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = frag(tb, wn * WTN + j * 16 + (lane & 15), chunk);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // Accumulator element (i, j, r) of this lane is C[row][col] with
+  //   row = m0 + wm*WTM + i*16 + (lane>>4)*4 + r,   col = n0 + wn*WTN + j*16 + (lane&15).
+  static __device__ __forceinline__ int acc_row(int i, int r) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    return (wave / WAVES_N) * WTM + i * 16 + (lane >> 4) * 4 + r;
+  }
+  static __device__ __forceinline__ int acc_col(int j) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    return (wave % WAVES_N) * WTN + j * 16 + (lane & 15);
+  }
+};
+
+// XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
+// a contiguous run of tile ids (bijective for any grid size).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}

@@ -1,0 +1,112 @@
+"""ctypes loader for libsnx.so (the C-ABI HIP library, see include/snx.h).
+
+The product path fails LOUDLY when the library is missing: there is no CPU or PyTorch fallback
+for any hot-path op."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: libsnx binds to the HIP runtime torch loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnx.so")
+
+P = C.c_void_p
+I32 = C.c_int32
+I64 = C.c_int64
+F32 = C.c_float
+SZ = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/snx.h one to one
+SIGNATURES = {
+    "snx_cast_bf16": (I32, [P, P, I64, P]),
+    "snx_cast_transpose_bf16": (I32, [P, P, I32, I32, P]),
+    "snx_gemm_nt_bf16": (I32, [P, P, P, I32, I32, I32, P]),
+    "snx_gemm_nt_resid": (I32, [P, P, P, P, I32, I32, I32, P]),
+    "snx_gemm_tn_accum": (I32, [P, P, P, I32, I32, I32, P]),
+    "snx_ln_fwd": (I32, [P, P, P, I32, I32, F32, P]),
+    "snx_embed_ln_fwd": (I32, [P, P, P, P, P, I32, I32, F32, P]),
+    "snx_gelu_ln_fwd": (I32, [P, P, P, I32, I32, F32, P]),
+    "snx_ln_bwd": (I32, [P, P, P, P, P, I32, I32, F32, I32, P]),
+    "snx_embed_ln_bwd": (I32, [P, P, P, P, P, P, I32, I32, F32, I32, P]),
+    "snx_gelu_ln_bwd": (I32, [P, P, P, P, P, I32, I32, F32, P]),
+    "snx_rope_inplace": (I32, [P, P, P, I32, I32, I32, P]),
+    "snx_geglu_fwd": (I32, [P, P, I32, I32, P]),
+    "snx_geglu_bwd": (I32, [P, P, P, I32, I32, P]),
+    "snx_attn_fwd": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
+    "snx_attn_bwd": (I32, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
+    "snx_splade_head_scratch_bytes": (SZ, [I32, I32]),
+    "snx_decoder_splade_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),
+    "snx_splade_bwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),
+    "snx_loss_workspace_bytes": (SZ, [I32, I32, I32]),
+    "snx_loss_fwd": (I32, [P, P, P, P, P, P, P, P, I32, I32, I32, P]),
+    "snx_loss_bwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, P]),
+    "snx_model_workspace_bytes": (SZ, [P, I32, I32]),
+    "snx_model_bwd_workspace_bytes": (SZ, [P, I32, I32]),
+    "snx_weight_cache_bytes": (SZ, [P]),
+    "snx_weight_cache_refresh": (I32, [P, P, P, P]),
+    "snx_model_forward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P]),
+    "snx_model_backward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P]),
+    "snx_adamw_clip_step": (I32, [P, P, P, P, P, I32, P, F32, F32, F32, F32, F32, F32, I32, P]),
+    "snx_version": (I32, []),
+}
+
+_lib = None
+
+
+class SnxLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """dlopen libsnx.so (once)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SnxLibraryError(
+                f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+                "`python opensearch-neural-pre-train_amd/snx/build.py` (or __graft_entry__.build()). "
+                "There is no CPU fallback for the product path.")
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+_bound = {}
+
+
+def fn(name: str):
+    """Typed entry point ``name`` of the C ABI."""
+    f = _bound.get(name)
+    if f is None:
+        res, args = SIGNATURES[name]
+        try:
+            f = getattr(lib(), name)
+        except AttributeError as e:
+            raise SnxLibraryError(f"libsnx.so does not export {name}; rebuild it") from e
+        f.restype = res
+        f.argtypes = args
+        _bound[name] = f
+    return f
+
+
+def verify_exports():
+    """Every symbol declared in include/snx.h must be exported (used by the CPU test-suite)."""
+    return [n for n in SIGNATURES if not hasattr(lib(), n)]
+
+
+def exported_symbols():
+    return list(SIGNATURES.keys())
+
+
+class SnxError(RuntimeError):
+    pass
+
+
+_CODES = {-2: "SNX_E_SHAPE (operand shapes violate kernel tiling assumptions)",
+          -3: "SNX_E_ARG (null or inconsistent argument)"}
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise SnxError(f"{what} failed: {_CODES.get(code, f'hipError {code}')}")

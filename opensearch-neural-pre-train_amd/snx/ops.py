@@ -1,0 +1,245 @@
+"""Tensor-level wrappers over the C ABI (one function per exported op).
+
+Each wrapper validates device / dtype / contiguity / shapes on the host BEFORE the launch (a
+mis-shaped operand must raise here, never fault on the GPU), allocates outputs with torch and
+launches on torch's current stream."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import check, fn
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(t: torch.Tensor, dtype, name: str, shape=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA(HIP) tensor")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+# ----------------------------------------------------------------------------- casts
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(fn("snx_cast_bf16")(_p(x), _p(out), x.numel(), _stream()), "snx_cast_bf16")
+    return out
+
+
+def cast_transpose_bf16(w: torch.Tensor) -> torch.Tensor:
+    _chk(w, torch.float32, "w")
+    R, Cc = w.shape
+    out = torch.empty((Cc, R), dtype=BF16, device=w.device)
+    check(fn("snx_cast_transpose_bf16")(_p(w), _p(out), R, Cc, _stream()), "snx_cast_transpose_bf16")
+    return out
+
+
+# ----------------------------------------------------------------------------- GEMMs
+def gemm_nt(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """C[M,N] = A[M,K] @ B[N,K]^T, bf16 in / fp32 accumulate / bf16 out."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    M, K = a.shape
+    N, K2 = b.shape
+    if K != K2 or K % 64:
+        raise ValueError(f"gemm_nt: K mismatch or K % 64 != 0 ({K}, {K2})")
+    c = torch.empty((M, N), dtype=BF16, device=a.device)
+    check(fn("snx_gemm_nt_bf16")(_p(a), _p(b), _p(c), M, N, K, _stream()), "snx_gemm_nt_bf16")
+    return c
+
+
+def gemm_nt_resid(a: torch.Tensor, b: torch.Tensor, h_in: torch.Tensor) -> torch.Tensor:
+    """h_out = h_in + bf16(A @ B^T)  (fp32 residual stream)."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    M, K = a.shape
+    N, K2 = b.shape
+    if K != K2 or K % 64:
+        raise ValueError("gemm_nt_resid: bad K")
+    _chk(h_in, torch.float32, "h_in", (M, N))
+    h_out = torch.empty_like(h_in)
+    check(fn("snx_gemm_nt_resid")(_p(a), _p(b), _p(h_in), _p(h_out), M, N, K, _stream()), "snx_gemm_nt_resid")
+    return h_out
+
+
+def gemm_tn_accum(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor) -> None:
+    """dw[N,K] += dy[M,N]^T @ x[M,K]  (fp32 accumulate into the gradient buffer)."""
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x")
+    M, N = dy.shape
+    M2, K = x.shape
+    if M != M2:
+        raise ValueError("gemm_tn_accum: row mismatch")
+    _chk(dw, torch.float32, "dw", (N, K))
+    check(fn("snx_gemm_tn_accum")(_p(dy), _p(x), _p(dw), M, N, K, _stream()), "snx_gemm_tn_accum")
+
+
+# ----------------------------------------------------------------------------- norms
+def ln_fwd(h: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    _chk(h, torch.float32, "h"); T, H = h.shape
+    _chk(w, torch.float32, "w", (H,))
+    x = torch.empty((T, H), dtype=BF16, device=h.device)
+    check(fn("snx_ln_fwd")(_p(h), _p(w), _p(x), T, H, eps, _stream()), "snx_ln_fwd")
+    return x
+
+
+def embed_ln_fwd(ids: torch.Tensor, E: torch.Tensor, w: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    _chk(ids, torch.int64, "ids"); _chk(E, torch.float32, "E")
+    V, H = E.shape
+    _chk(w, torch.float32, "w", (H,))
+    if int(ids.min()) < 0 or int(ids.max()) >= V:
+        raise ValueError("embed_ln_fwd: token id out of range")
+    T = ids.numel()
+    h = torch.empty((T, H), dtype=torch.float32, device=E.device)
+    x0 = torch.empty((T, H), dtype=BF16, device=E.device)
+    check(fn("snx_embed_ln_fwd")(_p(ids), _p(E), _p(w), _p(h), _p(x0), T, H, eps, _stream()), "snx_embed_ln_fwd")
+    return h, x0
+
+
+def gelu_ln_fwd(d: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    _chk(d, BF16, "d"); T, H = d.shape
+    _chk(w, torch.float32, "w", (H,))
+    x = torch.empty((T, H), dtype=BF16, device=d.device)
+    check(fn("snx_gelu_ln_fwd")(_p(d), _p(w), _p(x), T, H, eps, _stream()), "snx_gelu_ln_fwd")
+    return x
+
+
+def ln_bwd(dy: torch.Tensor, h: torch.Tensor, w: torch.Tensor, dh: torch.Tensor, dw: torch.Tensor, eps: float,
+           overwrite: bool = False) -> None:
+    """dh (+)= LN_bwd(dy; h, w);  dw += sum_t dy * xhat."""
+    _chk(h, torch.float32, "h"); T, H = h.shape
+    _chk(dy, BF16, "dy", (T, H)); _chk(w, torch.float32, "w", (H,))
+    _chk(dh, torch.float32, "dh", (T, H)); _chk(dw, torch.float32, "dw", (H,))
+    check(fn("snx_ln_bwd")(_p(dy), _p(h), _p(w), _p(dh), _p(dw), T, H, eps, int(overwrite), _stream()), "snx_ln_bwd")
+
+
+def embed_ln_bwd(dh: torch.Tensor, ids: torch.Tensor, E: torch.Tensor, w: torch.Tensor, gradE: torch.Tensor,
+                 dw: torch.Tensor, eps: float, pad_id: int) -> None:
+    _chk(dh, torch.float32, "dh"); T, H = dh.shape
+    _chk(ids, torch.int64, "ids"); _chk(E, torch.float32, "E"); _chk(gradE, torch.float32, "gradE", E.shape)
+    _chk(w, torch.float32, "w", (H,)); _chk(dw, torch.float32, "dw", (H,))
+    if ids.numel() != T:
+        raise ValueError("embed_ln_bwd: ids/dh row mismatch")
+    check(fn("snx_embed_ln_bwd")(_p(dh), _p(ids), _p(E), _p(w), _p(gradE), _p(dw), T, H, eps, pad_id, _stream()),
+          "snx_embed_ln_bwd")
+
+
+def gelu_ln_bwd(dy: torch.Tensor, d: torch.Tensor, w: torch.Tensor, dw: torch.Tensor, eps: float) -> torch.Tensor:
+    _chk(d, BF16, "d"); T, H = d.shape
+    _chk(dy, BF16, "dy", (T, H)); _chk(w, torch.float32, "w", (H,)); _chk(dw, torch.float32, "dw", (H,))
+    dd = torch.empty_like(d)
+    check(fn("snx_gelu_ln_bwd")(_p(dy), _p(d), _p(w), _p(dd), _p(dw), T, H, eps, _stream()), "snx_gelu_ln_bwd")
+    return dd
+
+
+# ----------------------------------------------------------------------------- rope / geglu
+def rope_table(max_pos: int, head_dim: int, theta: float, device) -> torch.Tensor:
+    """[max_pos, head_dim/2, 2] fp32 (cos, sin), computed exactly as hf:136-163 does (fp32)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    freqs = torch.arange(max_pos, dtype=torch.float)[:, None] * inv_freq[None, :]
+    return torch.stack((freqs.cos(), freqs.sin()), dim=-1).contiguous().to(device)
+
+
+def rope_inplace(qkv: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, heads: int, inverse: bool = False) -> None:
+    _chk(qkv, BF16, "qkv"); T = qkv.shape[0]
+    if qkv.numel() != T * 3 * heads * 64:
+        raise ValueError("rope_inplace: qkv must be [T, 3*heads*64]")
+    _chk(table, torch.float32, "table"); _chk(pos, torch.int32, "pos", (T,))
+    if table.shape[1:] != (32, 2) or int(pos.max()) >= table.shape[0] or int(pos.min()) < 0:
+        raise ValueError("rope_inplace: position outside the cos/sin table")
+    check(fn("snx_rope_inplace")(_p(qkv), _p(table), _p(pos), T, heads, int(inverse), _stream()), "snx_rope_inplace")
+
+
+def geglu_fwd(u: torch.Tensor) -> torch.Tensor:
+    _chk(u, BF16, "u"); T, I2 = u.shape
+    y = torch.empty((T, I2 // 2), dtype=BF16, device=u.device)
+    check(fn("snx_geglu_fwd")(_p(u), _p(y), T, I2 // 2, _stream()), "snx_geglu_fwd")
+    return y
+
+
+def geglu_bwd(u: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _chk(u, BF16, "u"); T, I2 = u.shape
+    _chk(dy, BF16, "dy", (T, I2 // 2))
+    du = torch.empty_like(u)
+    check(fn("snx_geglu_bwd")(_p(u), _p(dy), _p(du), T, I2 // 2, _stream()), "snx_geglu_bwd")
+    return du
+
+
+# ----------------------------------------------------------------------------- attention
+def _check_seqs(cu: torch.Tensor, T: int, max_seqlen: int):
+    _chk(cu, torch.int32, "cu_seqlens")
+    c = cu.tolist()
+    if c[0] != 0 or c[-1] != T or any(b <= a for a, b in zip(c, c[1:])) or max(b - a for a, b in zip(c, c[1:])) > max_seqlen:
+        raise ValueError("cu_seqlens must start at 0, end at T, be increasing, with lengths <= max_seqlen")
+
+
+def attn_fwd(qkv: torch.Tensor, cu: torch.Tensor, mask: torch.Tensor, max_seqlen: int, heads: int,
+             window: int, validate: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """window < 0 -> global layer; else inclusive half-window."""
+    _chk(qkv, BF16, "qkv"); T = qkv.shape[0]
+    if qkv.numel() != T * 3 * heads * 64:
+        raise ValueError("attn_fwd: qkv must be [T, 3*heads*64]")
+    _chk(mask, torch.int64, "mask")
+    if mask.numel() != T:
+        raise ValueError("attn_fwd: mask must have T elements")
+    if validate:
+        _check_seqs(cu, T, max_seqlen)
+    nseq = cu.numel() - 1
+    out = torch.empty((T, heads * 64), dtype=BF16, device=qkv.device)
+    lse = torch.empty((heads, T), dtype=torch.float32, device=qkv.device)
+    check(fn("snx_attn_fwd")(_p(qkv), _p(cu), _p(mask), _p(out), _p(lse), T, nseq, max_seqlen, heads, 64, window,
+                             _stream()), "snx_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, cu, mask, max_seqlen: int, heads: int, window: int, validate: bool = True):
+    """Returns dqkv [T, 3*heads*64] bf16 (gradients w.r.t. the post-RoPE q, k and v)."""
+    _chk(qkv, BF16, "qkv"); T = qkv.shape[0]
+    _chk(out, BF16, "out", (T, heads * 64)); _chk(dout, BF16, "dout", (T, heads * 64))
+    _chk(lse, torch.float32, "lse", (heads, T)); _chk(mask, torch.int64, "mask")
+    if validate:
+        _check_seqs(cu, T, max_seqlen)
+    nseq = cu.numel() - 1
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((heads, T), dtype=torch.float32, device=qkv.device)
+    check(fn("snx_attn_bwd")(_p(qkv), _p(out), _p(dout), _p(lse), _p(cu), _p(mask), _p(delta), _p(dqkv), T, nseq,
+                             max_seqlen, heads, 64, window, _stream()), "snx_attn_bwd")
+    return dqkv
+
+
+# ----------------------------------------------------------------------------- SPLADE head
+def decoder_splade_fwd(hd: torch.Tensor, w_bf16: torch.Tensor, bias: torch.Tensor, cu: torch.Tensor,
+                       mask: torch.Tensor, max_seqlen: int, validate: bool = True):
+    """-> sparse_repr [nseq, V] fp32, keys [nseq, V] int32 (packed value|argmax), token_weights [T] fp32."""
+    _chk(hd, BF16, "hd"); T, K = hd.shape
+    _chk(w_bf16, BF16, "w"); V = w_bf16.shape[0]
+    if w_bf16.shape[1] != K:
+        raise ValueError("decoder_splade_fwd: K mismatch")
+    _chk(bias, torch.float32, "bias", (V,)); _chk(mask, torch.int64, "mask")
+    if mask.numel() != T:
+        raise ValueError("mask must have T elements")
+    if validate:
+        _check_seqs(cu, T, max_seqlen)
+    nseq = cu.numel() - 1
+    sparse = torch.empty((nseq, V), dtype=torch.float32, device=hd.device)
+    keys = torch.empty((nseq, V), dtype=torch.int32, device=hd.device)
+    tw = torch.empty((T,), dtype=torch.float32, device=hd.device)
+    nbytes = fn("snx_splade_head_scratch_bytes")(T, V)
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=hd.device)
+    check(fn("snx_decoder_splade_fwd")(_p(hd), _p(w_bf16), _p(bias), _p(cu), _p(mask), _p(sparse), _p(keys), _p(tw),
+                                       _p(scratch), T, nseq, max_seqlen, V, K, _stream()), "snx_decoder_splade_fwd")
+    return sparse, keys, tw

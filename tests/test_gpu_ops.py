@@ -1,0 +1,281 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against plain PyTorch / oracle math with
+the same bf16 cast points.  Needs a real MI355X:  pytest -m gpu."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from snx import ops
+    return ops
+
+
+def _ulp_close(got, ref, what, max_ulp=1.01, frac_exact=0.97):
+    """bf16 tensors produced from the same exact products: equal except for rare 1-ulp flips
+    caused by fp32 accumulation order."""
+    g, r = got.float(), ref.float()
+    ulp = torch.clamp(r.abs(), min=1e-30) * 2.0 ** -8 * 2
+    bad = ((g - r).abs() > max_ulp * ulp + 1e-6)
+    assert bad.sum().item() == 0, f"{what}: {bad.sum().item()} elements differ by >1 bf16 ulp, max {((g-r).abs()).max().item()}"
+    assert (g == r).float().mean().item() >= frac_exact, f"{what}: too few exact matches {(g == r).float().mean().item()}"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (200, 1000, 768), (4096, 2304, 768),
+                                   (130, 768, 1152), (1, 128, 64)])
+def test_gemm_nt(dev, M, N, K):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g).to(dev).to(BF16)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(BF16)
+    c = ops.gemm_nt(a, b)
+    ref = (a.float() @ b.float().t()).to(BF16)
+    _ulp_close(c, ref, f"gemm_nt {M}x{N}x{K}")
+
+
+def test_gemm_nt_layout_identity(dev):
+    """A = I (rectangular) with an ASYMMETRIC B catches a transposed C write."""
+    ops = _ops()
+    M, N, K = 128, 256, 128
+    a = torch.zeros(M, K, device=dev)
+    a[torch.arange(M), torch.arange(M)] = 1.0
+    b = (torch.arange(N * K, device=dev, dtype=torch.float32).reshape(N, K) % 251) - 125.0
+    c = ops.gemm_nt(a.to(BF16), b.to(BF16))
+    assert torch.equal(c.float(), b.to(BF16).float()[:, :M].t().contiguous())
+
+
+def test_gemm_nt_resid(dev):
+    ops = _ops()
+    M, N, K = 300, 768, 1152
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(M, K, generator=g).to(dev).to(BF16)
+    b = (torch.randn(N, K, generator=g) * 0.03).to(dev).to(BF16)
+    h = torch.randn(M, N, generator=g).to(dev)
+    out = ops.gemm_nt_resid(a, b, h)
+    ref = h + (a.float() @ b.float().t()).to(BF16).float()
+    assert (out - ref).abs().max().item() < 2e-2
+    assert ((out - ref).abs() > 1e-6).float().mean().item() < 0.03
+
+
+@pytest.mark.parametrize("T,H", [(7, 256), (1000, 768), (4097, 768)])
+def test_layernorm_fwd(dev, T, H):
+    ops = _ops()
+    g = torch.Generator().manual_seed(T)
+    h = (torch.randn(T, H, generator=g) * 3 + 0.5).to(dev)
+    w = (1 + 0.2 * torch.randn(H, generator=g)).to(dev)
+    x = ops.ln_fwd(h, w, 1e-5)
+    ref = torch.nn.functional.layer_norm(h, (H,), w, None, 1e-5)
+    assert (x.float() - ref).abs().max().item() < 2 ** -7 * ref.abs().max().item()
+    assert (x == ref.to(BF16)).float().mean().item() > 0.99
+
+
+def test_embed_ln_fwd(dev):
+    ops = _ops()
+    V, H, T = 1000, 768, 300
+    g = torch.Generator().manual_seed(1)
+    E = torch.randn(V, H, generator=g).to(dev) * 0.02
+    w = (1 + 0.2 * torch.randn(H, generator=g)).to(dev)
+    ids = torch.randint(0, V, (T,), generator=g).to(dev)
+    h, x0 = ops.embed_ln_fwd(ids, E, w, 1e-5)
+    ref = torch.nn.functional.layer_norm(E[ids], (H,), w, None, 1e-5)
+    assert (h - ref).abs().max().item() < 1e-5
+    assert (x0 == h.to(BF16)).all()
+
+
+def test_gelu_ln_fwd_bwd(dev):
+    ops = _ops()
+    T, H = 515, 768
+    g = torch.Generator().manual_seed(2)
+    d = torch.randn(T, H, generator=g).to(dev).to(BF16)
+    w = (1 + 0.2 * torch.randn(H, generator=g)).to(dev)
+    dy = (torch.randn(T, H, generator=g) * 0.1).to(dev).to(BF16)
+    x = ops.gelu_ln_fwd(d, w, 1e-5)
+    dl = d.float().requires_grad_(True)
+    wl = w.clone().requires_grad_(True)
+    ge = torch.nn.functional.gelu(dl).to(BF16)
+    ref = torch.nn.functional.layer_norm(ge.float(), (H,), wl, None, 1e-5)
+    assert (x == ref.to(BF16)).float().mean().item() > 0.98
+    assert (x.float() - ref).abs().max().item() < 0.05
+    ref.backward(dy.float())
+    dw = torch.zeros(H, device=dev)
+    dd = ops.gelu_ln_bwd(dy, d, w, dw, 1e-5)
+    assert torch.allclose(dw, wl.grad, rtol=2e-3, atol=2e-3)
+    err = (dd.float() - dl.grad).abs().max().item()
+    assert err < 2e-2 * dl.grad.abs().max().item() + 1e-3, err
+
+
+@pytest.mark.parametrize("T,H", [(333, 768), (64, 256)])
+def test_layernorm_bwd(dev, T, H):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    h = (torch.randn(T, H, generator=g) * 2).to(dev)
+    w = (1 + 0.2 * torch.randn(H, generator=g)).to(dev)
+    dy = (torch.randn(T, H, generator=g) * 0.1).to(dev).to(BF16)
+    dh0 = torch.randn(T, H, generator=g).to(dev)
+    hl, wl = h.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(hl, (H,), wl, None, 1e-5).backward(dy.float())
+    dh = dh0.clone()
+    dw = torch.zeros(H, device=dev)
+    ops.ln_bwd(dy, h, w, dh, dw, 1e-5)
+    assert torch.allclose(dh, dh0 + hl.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(dw, wl.grad, rtol=1e-3, atol=1e-4)
+    dh2 = torch.full_like(dh0, float("nan"))
+    dw2 = torch.zeros(H, device=dev)
+    ops.ln_bwd(dy, h, w, dh2, dw2, 1e-5, overwrite=True)
+    assert torch.allclose(dh2, hl.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_embed_ln_bwd(dev):
+    ops = _ops()
+    V, H, T, pad = 50, 256, 400, 49
+    g = torch.Generator().manual_seed(6)
+    E = torch.randn(V, H, generator=g).to(dev)
+    w = (1 + 0.2 * torch.randn(H, generator=g)).to(dev)
+    ids = torch.randint(0, V, (T,), generator=g).to(dev)
+    dh = torch.randn(T, H, generator=g).to(dev)
+    El, wl = E.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    emb = torch.nn.functional.embedding(ids, El, padding_idx=pad)
+    torch.nn.functional.layer_norm(emb, (H,), wl, None, 1e-5).backward(dh)
+    gE = torch.zeros_like(E)
+    dw = torch.zeros(H, device=dev)
+    ops.embed_ln_bwd(dh, ids, E, w, gE, dw, 1e-5, pad)
+    assert torch.allclose(gE, El.grad, rtol=1e-3, atol=1e-4)
+    assert gE[pad].abs().max().item() == 0.0
+    assert torch.allclose(dw, wl.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_rope(dev):
+    from oracle import splade_oracle as O
+    ops = _ops()
+    B, S, heads = 3, 70, 4
+    T = B * S
+    g = torch.Generator().manual_seed(8)
+    qkv = torch.randn(T, 3 * heads * 64, generator=g).to(BF16)
+    pos = torch.arange(S, dtype=torch.int32).repeat(B)
+    for theta in (10000.0, 160000.0):
+        tab = ops.rope_table(128, 64, theta, dev)
+        x = qkv.to(dev).clone()
+        ops.rope_inplace(x, tab, pos.to(dev), heads)
+        cos, sin = O.rope_tables(S, 64, theta)
+        v = qkv.view(B, S, 3, heads, 64)
+        ref = v.clone()
+        for which in (0, 1):
+            t = v[:, :, which].transpose(1, 2)                     # [B, heads, S, 64]
+            ref[:, :, which] = O._apply_rope(t, cos, sin).transpose(1, 2)
+        got = x.cpu().view(B, S, 3, heads, 64)
+        assert torch.equal(got[:, :, 2], v[:, :, 2])               # v untouched
+        diff = (got.float() - ref.float()).abs()
+        assert diff.max().item() <= 2 ** -7 * 8 and (diff > 0).float().mean().item() < 0.01
+        ops.rope_inplace(x, tab, pos.to(dev), heads, inverse=True)  # rotation is orthogonal
+        assert (x.cpu().float() - qkv.float()).abs().max().item() < 0.06
+
+
+def test_geglu(dev):
+    ops = _ops()
+    T, I = 257, 1152
+    g = torch.Generator().manual_seed(9)
+    u = torch.randn(T, 2 * I, generator=g).to(dev).to(BF16)
+    dy = torch.randn(T, I, generator=g).to(dev).to(BF16)
+    y = ops.geglu_fwd(u)
+    a, gate = u.float().chunk(2, dim=-1)
+    act = torch.nn.functional.gelu(a).to(BF16)
+    ref = (act.float() * gate).to(BF16)
+    assert torch.equal(y, ref) or (y.float() - ref.float()).abs().max().item() < 2 ** -6
+    du = ops.geglu_bwd(u, dy)
+    ul = u.float().requires_grad_(True)
+    a2, g2 = ul.chunk(2, dim=-1)
+    (torch.nn.functional.gelu(a2) * g2).backward(dy.float())
+    err = (du.float() - ul.grad).abs().max().item()
+    assert err < 0.03 * ul.grad.abs().max().item()
+
+
+def _ragged(B, S, seed, min_len=1):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(min_len, S + 1, (B,), generator=g)
+    lens[0] = S
+    if B > 1:
+        lens[1] = 1
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    return lens, mask
+
+
+@pytest.mark.parametrize("S,window", [(64, -1), (64, 64), (256, -1), (256, 64), (200, 8), (130, -1), (512, 64)])
+def test_attention_fwd(dev, S, window):
+    from oracle import splade_oracle as O
+    ops = _ops()
+    B, heads = 4, 3
+    T = B * S
+    lens, mask = _ragged(B, S, S + window)
+    g = torch.Generator().manual_seed(11)
+    qkv = (torch.randn(T, 3 * heads * 64, generator=g) * 1.5).to(BF16)
+    cu = (torch.arange(B + 1, dtype=torch.int32) * S)
+    out, lse = ops.attn_fwd(qkv.to(dev), cu.to(dev), mask.reshape(-1).to(dev), S, heads, window)
+    v = qkv.view(B, S, 3, heads, 64)
+    q, k, vv = (v[:, :, i].transpose(1, 2) for i in range(3))
+    vis = O.attention_bias(mask, None if window < 0 else window)
+    ref = O._attention(q, k, vv, vis, 0.125, "bf16").transpose(1, 2).reshape(T, heads * 64)
+    valid = mask.reshape(-1).bool()
+    got = out.cpu().float()[valid]
+    exp = ref.float()[valid]
+    assert torch.isfinite(out.float()).all()
+    err = (got - exp).abs().max().item()
+    assert err < 0.03, err
+    assert ((got - exp).abs() > 2 ** -7 * exp.abs().clamp(min=0.25)).float().mean().item() < 0.02
+    # lse check on valid rows
+    s = (q.float() @ k.float().transpose(-1, -2)) * 0.125
+    s = s.masked_fill(~vis, float("-inf"))
+    lse_ref = torch.logsumexp(s, dim=-1).permute(1, 0, 2).reshape(heads, T)
+    assert (lse.cpu()[:, valid] - lse_ref[:, valid]).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("B,S,V,K", [(3, 64, 1000, 256), (4, 256, 1000, 768), (2, 200, 50000, 768), (5, 40, 777, 256),
+                                     (2, 300, 640, 256)])
+def test_decoder_splade_fwd(dev, B, S, V, K):
+    ops = _ops()
+    T = B * S
+    lens, mask = _ragged(B, S, V)
+    g = torch.Generator().manual_seed(13)
+    hd = torch.randn(T, K, generator=g).to(BF16)
+    W = (torch.randn(V, K, generator=g) * 0.05).to(BF16)
+    bias = torch.randn(V, generator=g) * 0.3
+    cu = torch.arange(B + 1, dtype=torch.int32) * S
+    sp, keys, tw = ops.decoder_splade_fwd(hd.to(dev), W.to(dev), bias.to(dev), cu.to(dev), mask.reshape(-1).to(dev), S)
+    logits = ((hd.to(dev).float() @ W.to(dev).float().t()) + bias.to(dev).to(BF16).float()).to(BF16)   # [T, V]
+    sc = torch.log1p(torch.relu(logits).float()).view(B, S, V) * mask.to(dev)[:, :, None].float()
+    ref_sp = sc.max(dim=1).values
+    ref_tw = sc.max(dim=-1).values.reshape(T)
+    # fp32 accumulation-order flips move a bf16 logit by one ulp at most
+    d = (sp - ref_sp).abs()
+    assert d.max().item() < 0.02, d.max().item()
+    assert (d > 1e-6).float().mean().item() < 0.02
+    dt = (tw - ref_tw).abs()
+    assert dt.max().item() < 0.02 and (dt > 1e-6).float().mean().item() < 0.03
+    assert (tw[mask.reshape(-1).to(dev) == 0] == 0).all()
+    # packed keys: value bits reproduce sparse exactly; argmax row is a valid row attaining the max
+    kk = keys.to(torch.int64) & 0xFFFFFFFF
+    bits = (kk >> 16).to(torch.int32)
+    val = (bits << 16).view(torch.float32)
+    assert torch.equal(torch.log1p(val), sp)
+    row = (0xFFFF - (kk & 0xFFFF)).clamp(max=S - 1)
+    pos = val > 0
+    relu_logits = torch.relu(logits).float().view(B, S, V)
+    at_row = torch.gather(relu_logits, 1, row.view(B, 1, V)).view(B, V)
+    assert torch.equal(at_row[pos], val[pos]) or ((at_row[pos] - val[pos]).abs() <= 2 ** -7 * val[pos]).all()
+    assert (torch.gather(mask.to(dev), 1, row)[pos] == 1).all()
+    # first-index tie rule: no earlier valid row has the same (bf16) value
+    same = (relu_logits == val.view(B, 1, V)) & mask.to(dev)[:, :, None].bool()
+    first = torch.where(same.any(1), same.float().argmax(1), torch.zeros_like(row))
+    agree = (first == row) | ~pos | ((at_row - val).abs() > 0)
+    assert agree.float().mean().item() > 0.999
