@@ -1,7 +1,167 @@
-/* temporary minimal header during bring-up; the documented C ABI is written once all ops exist */
-#pragma once
-#include <stdint.h>
+/* snx.h -- C ABI of libsnx.so: the MI355X-native (gfx950) SPLADE-ModernBERT training hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI on this path -- its boundary is the
+ * Python class API of src/model/splade_modern.py and src/model/losses.py, which dispatches
+ * implicitly to aten/cuBLAS/SDPA kernels -- so each entry point below cites the reference
+ * statement(s) whose device work it replaces.  `ref:` = /root/reference, `hf:` =
+ * transformers/models/modernbert/modeling_modernbert.py (the third-party module the reference
+ * wraps at ref:src/model/splade_modern.py:38,69-73).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host];
+ *   - caller owns all buffers; nothing is allocated, freed or synchronised inside;
+ *   - work is enqueued on `stream` and is ordered with other work on that stream; re-entrant
+ *     across streams (no hidden global state), hipGraph-capturable;
+ *   - return 0 on success, a positive hipError_t if a launch failed, or a negative SNX_E_* code
+ *     when the arguments violate a kernel's shape assumptions (checked on the host BEFORE any
+ *     launch -- a mis-shaped call never reaches the GPU);
+ *   - bf16 tensors are raw uint16 storage (`void*`), row-major, contiguous; "T" is the number
+ *     of token rows (all sequences of a call laid end to end), sequence s owns rows
+ *     cu_seqlens[s] .. cu_seqlens[s+1]-1 (int32, nseq+1 entries, cu_seqlens[0]=0,
+ *     cu_seqlens[nseq]=T); `mask` is the reference's attention_mask flattened to [T] (int64,
+ *     1 = token, 0 = padding).
+ *   - constraints: head_dim == 64, hidden % 256 == 0 (<= 1024), intermediate % 64 == 0, GEMM K % 64 == 0,
+ *     sequence length <= 65535.
+ */
+#ifndef SNX_H_
+#define SNX_H_
 #include <stddef.h>
-#ifndef __HIP__
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if !defined(__HIP__) && !defined(HIP_INCLUDE_HIP_HIP_RUNTIME_API_H)
 typedef struct ihipStream_t* hipStream_t;
 #endif
+
+#define SNX_E_SHAPE (-2)
+#define SNX_E_ARG (-3)
+#define SNX_FWD_SAVE_FOR_BACKWARD 1
+
+/* Architecture constants (ref:huggingface/v33/config.json; hf configuration_modernbert.py:113-162).
+ * layer l is a global-attention layer iff l % global_every == 0; `window` is the HALF window
+ * (local_attention / 2): key j visible to query i iff |i-j| <= window. */
+typedef struct snx_model_desc {
+  int32_t vocab, hidden, inter, layers, heads, head_dim;
+  int32_t global_every, window, pad_id, reserved0;
+  float ln_eps, reserved1;
+} snx_model_desc;
+
+int snx_version(void);
+
+/* Number of parameter tensors in the canonical order used by `params` / `grads` arrays:
+ *   tok_embeddings.weight, embeddings.norm.weight, then per layer [attn_norm.weight (l>=1)],
+ *   attn.Wqkv.weight, attn.Wo.weight, mlp_norm.weight, mlp.Wi.weight, mlp.Wo.weight, then
+ *   final_norm.weight, head.dense.weight, head.norm.weight, decoder.bias
+ * (= the reference state-dict order, the tied decoder.weight counted once). */
+int32_t snx_param_count(const snx_model_desc* d);
+
+/* ---- whole-model entry points (native layer loop) --------------------------------------- */
+
+/* bf16 copies of the fp32 master weights ([out,in] and transposed), refreshed after every
+ * optimizer step.  Replaces autocast's per-forward weight casts (ref:train_v33_ddp.py:337). */
+size_t snx_weight_cache_bytes(const snx_model_desc* d);
+int snx_weight_cache_refresh(const snx_model_desc* d, const void* const* params /*[host] fp32 device ptrs*/,
+                             void* cache, hipStream_t stream);
+
+/* Activation arena size for one forward over T token rows (save_for_bwd=0: inference plan). */
+size_t snx_model_workspace_bytes(const snx_model_desc* d, int32_t T, int32_t nseq, int32_t save_for_bwd);
+size_t snx_model_bwd_workspace_bytes(const snx_model_desc* d, int32_t T, int32_t nseq);
+
+/* SPLADEModernBERT.forward (ref:src/model/splade_modern.py:50-88):
+ *   ids,mask [T] int64; pos [T] int32 (position of each row inside its sequence);
+ *   rope_* [max_pos][32][2] fp32 (cos,sin) tables for theta_global / theta_local (hf:136-163);
+ *   -> sparse [nseq, vocab] fp32, token_weights [T] fp32; `saved` = arena (see above). */
+int snx_model_forward(const snx_model_desc* d, const void* const* params /*[host]*/, const void* wcache,
+                      const int64_t* ids, const int64_t* mask, const int32_t* cu_seqlens, const int32_t* pos,
+                      const float* rope_global, const float* rope_local, void* saved, float* sparse,
+                      float* token_weights, void* reserved, int32_t T, int32_t nseq, int32_t max_seqlen,
+                      int32_t flags, hipStream_t stream);
+
+/* Backward of the above (the autograd graph of ref:src/model/splade_modern.py:69-86 and of the HF
+ * encoder): g_sparse [nseq, vocab] fp32 = dL/d sparse_repr; every grads[i] (fp32, same shape as
+ * params[i]) is ACCUMULATED into (+=).  token_weights is treated as non-differentiable. */
+int snx_model_backward(const snx_model_desc* d, const void* const* params /*[host]*/, void* const* grads /*[host]*/,
+                       const void* wcache, const int64_t* ids, const int64_t* mask, const int32_t* cu_seqlens,
+                       const int32_t* pos, const float* rope_global, const float* rope_local, const void* saved,
+                       const float* g_sparse, void* scratch, int32_t T, int32_t nseq, int32_t max_seqlen,
+                       hipStream_t stream);
+
+/* ---- SPLADELossV33 (ref:src/model/losses.py:183-297) ------------------------------------- */
+/* dims [host] = {B, Bp, k, V, label_off, bf16_mm}: q [B,V], p [Bp,V] (Bp > B: all-gathered
+ * positives for cross-GPU in-batch negatives, own rows start at label_off), n [B*k,V]; bf16_mm=1
+ * rounds the operands of the in-batch mm to bf16 as autocast does (ref:losses.py:155).
+ * hp [host] = {temperature, lambda_q(t), lambda_d(t), lambda_neg(t), lambda_margin_mse}
+ * (the lambda schedule ref:losses.py:75-90 is evaluated by the host caller).
+ * tpos [B], tneg [B*k] teacher scores or NULL (MarginMSE, ref:losses.py:92-134).
+ * out8 = {loss, infonce, flops_q, flops_d, flops_neg, margin_mse, nonzero_q, nonzero_d}. */
+size_t snx_loss_workspace_bytes(int32_t B, int32_t Bp, int32_t k, int32_t V);
+int snx_loss_fwd(const float* q, const float* p, const float* n, const float* tpos, const float* tneg,
+                 const float* hp /*[host]*/, const int32_t* dims /*[host]*/, void* workspace, float* out8,
+                 hipStream_t stream);
+/* gout = dL/dloss (device scalar); dq [B,V], dp [Bp,V], dn [B*k,V] are overwritten. */
+int snx_loss_bwd(const float* q, const float* p, const float* n, const float* gout, const float* hp /*[host]*/,
+                 const int32_t* dims /*[host]*/, void* workspace, float* dq, float* dp, float* dn,
+                 hipStream_t stream);
+
+/* ---- individual ops (used by the entry points above; exported for parity tests) ---------- */
+
+/* fp32 -> bf16 (autocast weight / activation cast) and fp32 [R,C] -> bf16 [C,R]. */
+int snx_cast_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
+int snx_cast_transpose_bf16(const float* in, void* out, int32_t R, int32_t C, hipStream_t stream);
+
+/* nn.Linear under autocast (hf:271,300,90-91,490): C[M,N] = A[M,K] B[N,K]^T, bf16, fp32 acc. */
+int snx_gemm_nt_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, hipStream_t stream);
+/* ... fused with the fp32 residual add of hf:331-332: Hout = Hin + bf16(A B^T). */
+int snx_gemm_nt_resid(const void* A, const void* B, const float* Hin, float* Hout, int32_t M, int32_t N, int32_t K,
+                      hipStream_t stream);
+/* weight gradient of a Linear: dW[N,K] += dY[M,N]^T X[M,K]  (N, K multiples of 128). */
+int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K, hipStream_t stream);
+
+/* LayerNorm without bias (hf:61,312,314,420,487), fp32 in -> bf16 out. */
+int snx_ln_fwd(const float* h, const float* w, void* x_out, int32_t T, int32_t H, float eps, hipStream_t stream);
+/* ModernBertEmbeddings.forward (hf:64-71): h = LN(E[ids]) fp32, x0 = bf16(h). */
+int snx_embed_ln_fwd(const int64_t* ids, const float* E, const float* w, float* h_out, void* x0_out, int32_t T,
+                     int32_t H, float eps, hipStream_t stream);
+/* ModernBertPredictionHead tail (hf:489-490): LN(gelu(d)). */
+int snx_gelu_ln_fwd(const void* d, const float* w, void* x_out, int32_t T, int32_t H, float eps, hipStream_t stream);
+/* backward of the three above; dh (+)= dx, dw += ... (overwrite=1: dh = dx). */
+int snx_ln_bwd(const void* dy, const float* h, const float* w, float* dh, float* dw, int32_t T, int32_t H, float eps,
+               int32_t overwrite, hipStream_t stream);
+int snx_embed_ln_bwd(const float* dh, const int64_t* ids, const float* E, const float* w, float* gradE, float* dw,
+                     int32_t T, int32_t H, float eps, int32_t pad_id, hipStream_t stream);
+int snx_gelu_ln_bwd(const void* dy, const void* d, const float* w, void* dd, float* dw, int32_t T, int32_t H,
+                    float eps, hipStream_t stream);
+
+/* apply_rotary_pos_emb (hf:196-219) in place on the q and k thirds of qkv [T,3,heads,64]. */
+int snx_rope_inplace(void* qkv, const float* cos_sin_tab, const int32_t* pos, int32_t T, int32_t heads,
+                     int32_t inverse, hipStream_t stream);
+
+/* ModernBertMLP GeGLU (hf:90-91): y = gelu(u[:, :I]) * u[:, I:], and its backward. */
+int snx_geglu_fwd(const void* u, void* y, int32_t T, int32_t I, hipStream_t stream);
+int snx_geglu_bwd(const void* u, const void* dy, void* du, int32_t T, int32_t I, hipStream_t stream);
+
+/* Attention (hf:286-297 -> SDPA; masks masking_utils.py:141-150).  window < 0: global layer. */
+int snx_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse, int32_t T,
+                 int32_t nseq, int32_t max_seqlen, int32_t heads, int32_t head_dim, int32_t window,
+                 hipStream_t stream);
+int snx_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
+                 const int64_t* mask, float* delta_scratch /*[heads,T]*/, void* dqkv, int32_t T, int32_t nseq,
+                 int32_t max_seqlen, int32_t heads, int32_t head_dim, int32_t window, hipStream_t stream);
+
+/* Tied decoder GEMM + SPLADE tail fused (hf:550 + ref:src/model/splade_modern.py:76-86). */
+size_t snx_splade_head_scratch_bytes(int32_t T, int32_t V);
+int snx_decoder_splade_fwd(const void* Hd, const void* W, const float* bias, const int32_t* cu_seqlens,
+                           const int64_t* mask, float* sparse, uint32_t* keys, float* token_weights, void* scratch,
+                           int32_t T, int32_t nseq, int32_t max_seqlen, int32_t V, int32_t K, hipStream_t stream);
+/* arg-max-routed backward: dHd [T,H] bf16 (overwritten), gradE [V,H] += , gradb [V] += . */
+int snx_splade_bwd(const float* g, const uint32_t* keys, const void* Hd, const void* W, const int32_t* cu_seqlens,
+                   void* dHd, float* gradE, float* gradb, void* reserved, int32_t T, int32_t nseq,
+                   int32_t max_seqlen, int32_t V, int32_t H, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNX_H_ */

@@ -179,3 +179,268 @@ extern "C" int snx_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const in
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }
+
+// ==========================================================================================
+// Backward.  P is recomputed from q, k and the forward's log-sum-exp; two passes so that no
+// gradient needs a cross-workgroup sum (deterministic, no atomics):
+//   attn_bwd_dq_kernel : one workgroup per 64 query rows, loops over key tiles     -> dQ
+//   attn_bwd_dkv_kernel: one workgroup per 64 keys,       loops over query tiles   -> dK, dV
+// dS = P o (dP - delta), delta_i = sum_d dO_i O_i;  dQ = scale dS K, dK = scale dS^T Q, dV = P^T dO.
+// Every tile that is read both row-wise (MFMA A operand along d) and transposed (contraction
+// over its row index) is staged twice, once per swizzle (k_off image for ds_read_b128 rows,
+// v_off image for ds_read_b64_tr_b16).
+// ==========================================================================================
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                  float* __restrict__ delta, int T, int heads) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)T * heads) return;
+  const int head = gid % heads;
+  const long t = gid / heads;
+  const bf16_t* po = o + (t * heads + head) * 64;
+  const bf16_t* pd = dout + (t * heads + head) * 64;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const bf16x8 a = *(const bf16x8*)(po + c * 8), b = *(const bf16x8*)(pd + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(b[e]);
+  }
+  delta[(long)head * T + t] = s;
+}
+
+// stage a 64x64 bf16 tile twice: row image (k_off) and transposed-read image (v_off)
+__device__ __forceinline__ void stage_dual(const bf16_t* __restrict__ base, long row_stride, int r0g, int rmax,
+                                           char* lds_row, char* lds_tr) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = threadIdx.x + i * 256;
+    const int r = id >> 3, c = id & 7;
+    int gr = r0g + r;
+    gr = gr < rmax ? gr : rmax - 1;
+    const bf16x8 v = *(const bf16x8*)(base + (long)gr * row_stride + c * 8);
+    if (lds_row) *(bf16x8*)(lds_row + k_off(r, c)) = v;
+    if (lds_tr) *(bf16x8*)(lds_tr + v_off(r, c)) = v;
+  }
+}
+
+// A-operand fragment of the TRANSPOSE of a [64 rows][64 d] tile (v_off image): MFMA row index =
+// d (16*dt + lane&15), contraction elements = tile rows 16*(2c + j/4) + 4g + j%4.
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int dt, int c, int lane) {
+  const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int r0 = 16 * (2 * c) + 4 * g + tq, r1 = r0 + 16;
+  const int chunk = 2 * dt + (tp >> 1);
+  const bf16x4 a0 = lds_tr16(tile + v_off(r0, chunk) + (tp & 1) * 8);
+  const bf16x4 a1 = lds_tr16(tile + v_off(r1, chunk) + (tp & 1) * 8);
+  return (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, const int32_t* __restrict__ cu_seqlens, const int64_t* __restrict__ mask,
+    bf16_t* __restrict__ dqkv, int T, int heads, int window, float scale) {
+  __shared__ __attribute__((aligned(16))) char sKr[64 * 128];
+  __shared__ __attribute__((aligned(16))) char sKt[64 * 128];
+  __shared__ __attribute__((aligned(16))) char sVr[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char sValid[64];
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= slen) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int H = heads * 64;
+  const long rs = 3L * H;
+  const bf16_t* qbase = qkv + (long)s0 * rs + head * 64;
+  const bf16_t* kbase = qbase + H;
+  const bf16_t* vbase = qbase + 2 * H;
+  const int qpos = q0 + wave * 16 + li;
+  const int qrow = qpos < slen ? qpos : slen - 1;
+  bf16x8 qf[2], dof[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    qf[c] = *(const bf16x8*)(qbase + (long)qrow * rs + c * 32 + g * 8);
+    dof[c] = *(const bf16x8*)(dout + (long)(s0 + qrow) * H + head * 64 + c * 32 + g * 8);
+  }
+  const float lse_q = lse[(long)head * T + s0 + qrow];
+  const float dl_q = delta[(long)head * T + s0 + qrow];
+
+  int j_lo = 0, j_hi = (slen - 1) >> 6;
+  if (window >= 0) {
+    const int lo = q0 - window, hi = q0 + 63 + window;
+    j_lo = lo > 0 ? (lo >> 6) : 0;
+    j_hi = (hi < slen - 1 ? hi : slen - 1) >> 6;
+  }
+  f32x4 dq[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int j = j_lo; j <= j_hi; ++j) {
+    const int key0 = j * 64;
+    __syncthreads();
+    stage_dual(kbase, rs, key0, slen, sKr, sKt);
+    stage_dual(vbase, rs, key0, slen, sVr, nullptr);
+    if (threadIdx.x < 64) {
+      const int key = key0 + threadIdx.x;
+      sValid[threadIdx.x] = (key < slen && mask[s0 + key] != 0) ? 1 : 0;
+    }
+    __syncthreads();
+    bf16x8 dsb[2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bf16x8 kf = *(const bf16x8*)(sKr + k_off(kt * 16 + li, 4 * c + g));
+        const bf16x8 vf = *(const bf16x8*)(sVr + k_off(kt * 16 + li, 4 * c + g));
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[c], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[c], dp, 0, 0, 0);
+      }
+      const uint32_t vm = *(const uint32_t*)(sValid + kt * 16 + g * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + kt * 16 + g * 4 + r;
+        bool ok = (vm >> (8 * r)) & 1;
+        if (window >= 0) {
+          const int dlt = qpos - key;
+          ok = ok && (dlt <= window) && (dlt >= -window);
+        }
+        const float p = ok ? __expf(s[r] * scale - lse_q) : 0.f;
+        dsb[kt >> 1][(kt & 1) * 4 + r] = f2bf(p * (dp[r] - dl_q));
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sKt, d, c, lane), dsb[c], dq[d], 0, 0, 0);
+  }
+  if (qpos < slen) {
+    bf16_t* orow = dqkv + (long)(s0 + qpos) * rs + head * 64 + g * 4;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      bf16x4 v = {f2bf(dq[d][0] * scale), f2bf(dq[d][1] * scale), f2bf(dq[d][2] * scale), f2bf(dq[d][3] * scale)};
+      *(bf16x4*)(orow + d * 16) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, const int32_t* __restrict__ cu_seqlens, const int64_t* __restrict__ mask,
+    bf16_t* __restrict__ dqkv, int T, int heads, int window, float scale) {
+  __shared__ __attribute__((aligned(16))) char sQr[64 * 128];
+  __shared__ __attribute__((aligned(16))) char sQt[64 * 128];
+  __shared__ __attribute__((aligned(16))) char sOr[64 * 128];
+  __shared__ __attribute__((aligned(16))) char sOt[64 * 128];
+  __shared__ __attribute__((aligned(16))) float sLse[64];
+  __shared__ __attribute__((aligned(16))) float sDel[64];
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
+  const int key0 = blockIdx.x * 64;
+  if (key0 >= slen) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int H = heads * 64;
+  const long rs = 3L * H;
+  const bf16_t* qbase = qkv + (long)s0 * rs + head * 64;
+  const bf16_t* kbase = qbase + H;
+  const bf16_t* vbase = qbase + 2 * H;
+  const bf16_t* dobase = dout + (long)s0 * H + head * 64;
+  const int kpos = key0 + wave * 16 + li;
+  const int krow = kpos < slen ? kpos : slen - 1;
+  const bool kvalid = kpos < slen && mask[s0 + krow] != 0;
+  bf16x8 kf[2], vf[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    kf[c] = *(const bf16x8*)(kbase + (long)krow * rs + c * 32 + g * 8);
+    vf[c] = *(const bf16x8*)(vbase + (long)krow * rs + c * 32 + g * 8);
+  }
+  int i_lo = 0, i_hi = (slen - 1) >> 6;
+  if (window >= 0) {
+    const int lo = key0 - window, hi = key0 + 63 + window;
+    i_lo = lo > 0 ? (lo >> 6) : 0;
+    i_hi = (hi < slen - 1 ? hi : slen - 1) >> 6;
+  }
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int i = i_lo; i <= i_hi; ++i) {
+    const int q0 = i * 64;
+    __syncthreads();
+    stage_dual(qbase, rs, q0, slen, sQr, sQt);
+    stage_dual(dobase, H, q0, slen, sOr, sOt);
+    if (threadIdx.x < 64) {
+      const int q = q0 + threadIdx.x;
+      const int qc = q < slen ? q : slen - 1;
+      sLse[threadIdx.x] = lse[(long)head * T + s0 + qc];
+      sDel[threadIdx.x] = delta[(long)head * T + s0 + qc];
+    }
+    __syncthreads();
+    bf16x8 pb[2], dsb[2];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bf16x8 qfr = *(const bf16x8*)(sQr + k_off(qt * 16 + li, 4 * c + g));
+        const bf16x8 ofr = *(const bf16x8*)(sOr + k_off(qt * 16 + li, 4 * c + g));
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[c], s, 0, 0, 0);     // S[q][key]
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[c], dp, 0, 0, 0);   // dP[q][key]
+      }
+      const f32x4 l4 = *(const f32x4*)(sLse + qt * 16 + g * 4);
+      const f32x4 d4 = *(const f32x4*)(sDel + qt * 16 + g * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = q0 + qt * 16 + g * 4 + r;
+        bool ok = kvalid && q < slen;
+        if (window >= 0) {
+          const int dlt = q - kpos;
+          ok = ok && (dlt <= window) && (dlt >= -window);
+        }
+        const float p = ok ? __expf(s[r] * scale - l4[r]) : 0.f;
+        pb[qt >> 1][(qt & 1) * 4 + r] = f2bf(p);
+        dsb[qt >> 1][(qt & 1) * 4 + r] = f2bf(p * (dp[r] - d4[r]));
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sOt, d, c, lane), pb[c], dv[d], 0, 0, 0);
+        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQt, d, c, lane), dsb[c], dk[d], 0, 0, 0);
+      }
+  }
+  if (kpos < slen) {
+    bf16_t* krow_out = dqkv + (long)(s0 + kpos) * rs + H + head * 64 + g * 4;
+    bf16_t* vrow_out = krow_out + H;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      bf16x4 a = {f2bf(dk[d][0] * scale), f2bf(dk[d][1] * scale), f2bf(dk[d][2] * scale), f2bf(dk[d][3] * scale)};
+      bf16x4 b = {f2bf(dv[d][0]), f2bf(dv[d][1]), f2bf(dv[d][2]), f2bf(dv[d][3])};
+      *(bf16x4*)(krow_out + d * 16) = a;
+      *(bf16x4*)(vrow_out + d * 16) = b;
+    }
+  }
+}
+
+extern "C" int snx_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                            const int32_t* cu_seqlens, const int64_t* mask, float* delta_scratch, void* dqkv,
+                            int32_t T, int32_t nseq, int32_t max_seqlen, int32_t heads, int32_t head_dim,
+                            int32_t window, hipStream_t st) {
+  if (!qkv || !out || !dout || !lse || !cu_seqlens || !mask || !delta_scratch || !dqkv) return SNX_E_ARG;
+  if (T <= 0 || nseq <= 0 || max_seqlen <= 0 || heads <= 0 || head_dim != 64) return SNX_E_SHAPE;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)T * heads, 256)), dim3(256), 0, st, (const bf16_t*)out,
+                     (const bf16_t*)dout, delta_scratch, T, heads);
+  SNX_CHECK_LAUNCH();
+  dim3 grid(cdiv(max_seqlen, 64), heads, nseq);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                     delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, T, heads, window, 0.125f);
+  SNX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                     delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, T, heads, window, 0.125f);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}

@@ -1,0 +1,309 @@
+// SPLADELossV33 on device (K12-K15 of SURVEY.md §2.3; ref:src/model/losses.py:57-297):
+//   InfoNCE over [in-batch positives | k hard negatives] + FLOPS(q) + FLOPS(pos) + FLOPS(neg)
+//   [+ MarginMSE], closed-form gradients, no host sync (scalars stay on the device).
+// Three launches: (1) per-vocab-chunk partial dot products / column means (LDS-staged tiles,
+// coalesced along V), (2) one workgroup reducing the partials, soft-max / cross-entropy and the
+// gradient coefficients, (3) the gradient of the three [*, V] inputs, again chunked over V.
+// `P` may hold MORE rows than the anchors (Bp >= B): the all-gathered positives of every rank
+// for cross-GPU in-batch negatives (config 4); labels are label_off + i.
+#include "common.h"
+#include "snx.h"
+
+struct LossDims {
+  int B, Bp, k, V, CH, nchunk, label_off, bf16_mm;
+  float inv_tau, lam_q, lam_d, lam_neg, lam_mm;
+};
+
+// workspace layout (floats)
+struct LossWs {
+  float *part_inb, *part_hard, *part_pos, *part_sc;   // [nchunk][B*Bp], [nchunk][B*k], [nchunk][B], [nchunk][8]
+  float *mean_q, *mean_p, *mean_n;                     // [V] each
+  float *G, *Gh, *dpos;                                // [B*Bp], [B*k], [B]
+};
+
+static inline size_t ws_floats(int B, int Bp, int k, int V, int nchunk) {
+  return (size_t)nchunk * ((size_t)B * Bp + (size_t)B * k + B + 8) + 3 * (size_t)V + (size_t)B * Bp + (size_t)B * k + B;
+}
+static inline LossWs carve(float* w, int B, int Bp, int k, int V, int nchunk) {
+  LossWs s;
+  s.part_inb = w; w += (size_t)nchunk * B * Bp;
+  s.part_hard = w; w += (size_t)nchunk * B * k;
+  s.part_pos = w; w += (size_t)nchunk * B;
+  s.part_sc = w; w += (size_t)nchunk * 8;
+  s.mean_q = w; w += V;
+  s.mean_p = w; w += V;
+  s.mean_n = w; w += V;
+  s.G = w; w += (size_t)B * Bp;
+  s.Gh = w; w += (size_t)B * k;
+  s.dpos = w;
+  return s;
+}
+static inline int pick_ch(int B, int Bp) {
+  int ch = 128;
+  while (ch > 16 && (size_t)(B + Bp) * ch * 4 > 96 * 1024) ch >>= 1;
+  return ch;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ q, const float* __restrict__ p,
+                                                           const float* __restrict__ n, LossDims d, LossWs w) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ float red[4];
+  const int LD = d.CH + 1;               // +1 float: row-strided reads stay conflict-free
+  float* sq = sm;                       // [B][LD]
+  float* sp = sm + d.B * LD;            // [Bp][LD]
+  const int c0 = blockIdx.x * d.CH;
+  const int cw = min(d.CH, d.V - c0);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < d.B * d.CH; i += 256) {
+    const int r = i / d.CH, c = i % d.CH;
+    sq[r * LD + c] = c < cw ? q[(long)r * d.V + c0 + c] : 0.f;
+  }
+  for (int i = tid; i < d.Bp * d.CH; i += 256) {
+    const int r = i / d.CH, c = i % d.CH;
+    sp[r * LD + c] = c < cw ? p[(long)r * d.V + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  // in-batch partial dots (operands rounded to bf16 when the reference's mm runs under autocast)
+  for (int pr = tid; pr < d.B * d.Bp; pr += 256) {
+    const int i = pr / d.Bp, j = pr % d.Bp;
+    const float* a = sq + i * LD;
+    const float* b = sp + j * LD;
+    float s = 0.f;
+    if (d.bf16_mm) {
+      for (int c = 0; c < d.CH; ++c) s += rbf(a[c]) * rbf(b[c]);
+    } else {
+      for (int c = 0; c < d.CH; ++c) s += a[c] * b[c];
+    }
+    w.part_inb[(long)blockIdx.x * d.B * d.Bp + pr] = s;
+  }
+  // q.p (own positive, fp32) for MarginMSE: positives of this rank start at row label_off
+  for (int i = tid; i < d.B; i += 256) {
+    const float* a = sq + i * LD;
+    const float* b = sp + (d.label_off + i) * LD;
+    float s = 0.f;
+    for (int c = 0; c < d.CH; ++c) s += a[c] * b[c];
+    w.part_pos[(long)blockIdx.x * d.B + i] = s;
+  }
+  // hard-negative dots: one wave per (i, kk) pair, lanes along the chunk
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int pr = wave; pr < d.B * d.k; pr += 4) {
+    const int i = pr / d.k;
+    const float* nr = n + (long)pr * d.V + c0;
+    float s = 0.f;
+    for (int c = lane; c < cw; c += 64) s += sq[i * LD + c] * nr[c];
+    s = wave_sum(s);
+    if (lane == 0) w.part_hard[(long)blockIdx.x * d.B * d.k + pr] = s;
+  }
+  // column means (complete: the chunk holds every row), FLOPS partials, non-zero counts
+  float fq = 0.f, fp = 0.f, fn = 0.f, zq = 0.f, zp = 0.f;
+  for (int c = tid; c < cw; c += 256) {
+    float cq = 0.f, cp = 0.f, cn = 0.f;
+    for (int r = 0; r < d.B; ++r) {
+      const float a = sq[r * LD + c], b = sp[(d.label_off + r) * LD + c];
+      cq += a; cp += b;
+      zq += a > 0.f ? 1.f : 0.f;
+      zp += b > 0.f ? 1.f : 0.f;
+    }
+    for (int r = 0; r < d.B * d.k; ++r) cn += n[(long)r * d.V + c0 + c];
+    cq /= (float)d.B; cp /= (float)d.B; cn /= (float)(d.B * d.k);
+    w.mean_q[c0 + c] = cq; w.mean_p[c0 + c] = cp; w.mean_n[c0 + c] = cn;
+    fq += cq * cq; fp += cp * cp; fn += cn * cn;
+  }
+  fq = block_sum(fq, red); fp = block_sum(fp, red); fn = block_sum(fn, red);
+  zq = block_sum(zq, red); zp = block_sum(zp, red);
+  if (tid == 0) {
+    float* o = w.part_sc + (long)blockIdx.x * 8;
+    o[0] = fq; o[1] = fp; o[2] = fn; o[3] = zq; o[4] = zp;
+  }
+}
+
+// out[0]=loss [1]=infonce [2]=flops_q [3]=flops_d [4]=flops_neg [5]=margin_mse [6]=nonzero_q [7]=nonzero_d
+__global__ __launch_bounds__(256) void loss_reduce_kernel(LossDims d, LossWs w, const float* __restrict__ tpos,
+                                                          const float* __restrict__ tneg, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int NS = d.Bp + d.k;                // columns of the score matrix
+  float* sc = sm;                           // [B][NS]
+  float* hard_raw = sm + d.B * NS;          // [B][k]  (un-tempered q.n)
+  float* posd = hard_raw + d.B * d.k;       // [B]
+  for (int pr = tid; pr < d.B * d.Bp; pr += 256) {
+    float s = 0.f;
+    for (int c = 0; c < d.nchunk; ++c) s += w.part_inb[(long)c * d.B * d.Bp + pr];
+    if (d.bf16_mm) s = rbf(s);
+    sc[(pr / d.Bp) * NS + (pr % d.Bp)] = s * d.inv_tau;
+  }
+  for (int pr = tid; pr < d.B * d.k; pr += 256) {
+    float s = 0.f;
+    for (int c = 0; c < d.nchunk; ++c) s += w.part_hard[(long)c * d.B * d.k + pr];
+    hard_raw[pr] = s;
+    sc[(pr / d.k) * NS + d.Bp + (pr % d.k)] = s * d.inv_tau;
+  }
+  for (int i = tid; i < d.B; i += 256) {
+    float s = 0.f;
+    for (int c = 0; c < d.nchunk; ++c) s += w.part_pos[(long)c * d.B + i];
+    posd[i] = s;
+  }
+  float sca[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int c = tid; c < d.nchunk; c += 256)
+    for (int e = 0; e < 5; ++e) sca[e] += w.part_sc[(long)c * 8 + e];
+  float tot[5];
+  for (int e = 0; e < 5; ++e) tot[e] = block_sum(sca[e], red);
+  __syncthreads();
+  // cross entropy, one row per thread; soft-max gradient coefficients
+  float ce = 0.f, mm = 0.f;
+  for (int i = tid; i < d.B; i += 256) {
+    float* row = sc + i * NS;
+    float mx = row[0];
+    for (int j = 1; j < NS; ++j) mx = fmaxf(mx, row[j]);
+    float se = 0.f;
+    for (int j = 0; j < NS; ++j) se += expf(row[j] - mx);
+    const float lse = mx + logf(se);
+    const int lab = d.label_off + i;
+    ce += lse - row[lab];
+    const float gscale = d.inv_tau / (float)d.B;
+    for (int j = 0; j < d.Bp; ++j) {
+      float gv = (expf(row[j] - lse) - (j == lab ? 1.f : 0.f)) * gscale;
+      if (d.bf16_mm) gv = rbf(gv);
+      w.G[(long)i * d.Bp + j] = gv;
+    }
+    float dps = 0.f;
+    for (int kk = 0; kk < d.k; ++kk) {
+      float gh = expf(row[d.Bp + kk] - lse) * gscale;
+      if (d.lam_mm > 0.f && tpos && tneg) {
+        const float smg = posd[i] - hard_raw[i * d.k + kk];
+        const float tmg = tpos[i] - tneg[i * d.k + kk];
+        const float df = smg - tmg;
+        mm += df * df;
+        const float dsm = d.lam_mm * 2.f * df / (float)(d.B * d.k);
+        dps += dsm;
+        gh -= dsm;
+      }
+      w.Gh[(long)i * d.k + kk] = gh;
+    }
+    w.dpos[i] = dps;
+  }
+  ce = block_sum(ce, red);
+  mm = block_sum(mm, red);
+  if (tid == 0) {
+    const float infonce = ce / (float)d.B;
+    const float mmse = mm / (float)(d.B * d.k);
+    out[1] = infonce; out[2] = tot[0]; out[3] = tot[1]; out[4] = tot[2]; out[5] = mmse;
+    out[6] = tot[3] / (float)d.B; out[7] = tot[4] / (float)d.B;
+    out[0] = infonce + d.lam_q * tot[0] + d.lam_d * tot[1] + d.lam_neg * tot[2] +
+             ((d.lam_mm > 0.f && tpos && tneg) ? d.lam_mm * mmse : 0.f);
+  }
+}
+
+// gradients of the three inputs; gout = dL/dloss (device scalar)
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ q, const float* __restrict__ p,
+                                                       const float* __restrict__ n, const float* __restrict__ gout,
+                                                       LossDims d, LossWs w, float* __restrict__ dq,
+                                                       float* __restrict__ dp, float* __restrict__ dn) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int LD = d.CH + 1;
+  float* sq = sm;                       // [B][LD]
+  float* sp = sm + d.B * LD;            // [Bp][LD]
+  const int c0 = blockIdx.x * d.CH;
+  const int cw = min(d.CH, d.V - c0);
+  const int tid = threadIdx.x;
+  const float go = gout[0];
+  for (int i = tid; i < d.B * d.CH; i += 256) {
+    const int r = i / d.CH, c = i % d.CH;
+    sq[r * LD + c] = c < cw ? q[(long)r * d.V + c0 + c] : 0.f;
+  }
+  for (int i = tid; i < d.Bp * d.CH; i += 256) {
+    const int r = i / d.CH, c = i % d.CH;
+    sp[r * LD + c] = c < cw ? p[(long)r * d.V + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  const float fq = 2.f * d.lam_q / (float)d.B, fd = 2.f * d.lam_d / (float)d.B;
+  const float fn = 2.f * d.lam_neg / (float)(d.B * d.k);
+  // dq
+  for (int o = tid; o < d.B * d.CH; o += 256) {
+    const int i = o / d.CH, c = o % d.CH;
+    if (c >= cw) continue;
+    float s = 0.f;
+    const float* Gi = w.G + (long)i * d.Bp;
+    for (int j = 0; j < d.Bp; ++j) s += Gi[j] * (d.bf16_mm ? rbf(sp[j * LD + c]) : sp[j * LD + c]);
+    if (d.bf16_mm) s = rbf(s);
+    for (int kk = 0; kk < d.k; ++kk) s += w.Gh[i * d.k + kk] * n[(long)(i * d.k + kk) * d.V + c0 + c];
+    s += w.dpos[i] * sp[(d.label_off + i) * LD + c] + fq * w.mean_q[c0 + c];
+    dq[(long)i * d.V + c0 + c] = go * s;
+  }
+  // dp (all Bp rows: remote rows receive only the in-batch term)
+  for (int o = tid; o < d.Bp * d.CH; o += 256) {
+    const int j = o / d.CH, c = o % d.CH;
+    if (c >= cw) continue;
+    float s = 0.f;
+    for (int i = 0; i < d.B; ++i) s += w.G[(long)i * d.Bp + j] * (d.bf16_mm ? rbf(sq[i * LD + c]) : sq[i * LD + c]);
+    if (d.bf16_mm) s = rbf(s);
+    const int il = j - d.label_off;
+    if (il >= 0 && il < d.B) s += w.dpos[il] * sq[il * LD + c] + fd * w.mean_p[c0 + c];
+    dp[(long)j * d.V + c0 + c] = go * s;
+  }
+  // dn
+  for (int o = tid; o < d.B * d.k * d.CH; o += 256) {
+    const int r = o / d.CH, c = o % d.CH;
+    if (c >= cw) continue;
+    const int i = r / d.k;
+    dn[(long)r * d.V + c0 + c] = go * (w.Gh[r] * sq[i * LD + c] + fn * w.mean_n[c0 + c]);
+  }
+}
+
+static int make_dims(LossDims& d, int B, int Bp, int k, int V, int label_off, int bf16_mm, const float* hp) {
+  if (B <= 0 || Bp < B || k <= 0 || V <= 0 || label_off < 0 || label_off + B > Bp) return SNX_E_SHAPE;
+  if (B > 256 || Bp > 1024 || k > 16) return SNX_E_SHAPE;
+  d.B = B; d.Bp = Bp; d.k = k; d.V = V; d.label_off = label_off; d.bf16_mm = bf16_mm;
+  d.CH = pick_ch(B, Bp);
+  d.nchunk = cdiv(V, d.CH);
+  d.inv_tau = 1.0f / hp[0]; d.lam_q = hp[1]; d.lam_d = hp[2]; d.lam_neg = hp[3]; d.lam_mm = hp[4];
+  if ((size_t)(B * (Bp + k) + B * k + B) * 4 > 150 * 1024) return SNX_E_SHAPE;
+  return SNX_OK;
+}
+
+extern "C" size_t snx_loss_workspace_bytes(int32_t B, int32_t Bp, int32_t k, int32_t V) {
+  if (B <= 0 || Bp < B || k <= 0 || V <= 0) return 0;
+  const int ch = pick_ch(B, Bp);
+  return ws_floats(B, Bp, k, V, cdiv(V, ch)) * sizeof(float);
+}
+
+// hp = {temperature, lambda_q(t), lambda_d(t), lambda_neg(t), lambda_margin_mse}  (host floats)
+// dims = {B, Bp, k, V, label_off, bf16_mm}
+extern "C" int snx_loss_fwd(const float* q, const float* p, const float* n, const float* tpos, const float* tneg,
+                            const float* hp, const int32_t* dims, void* workspace, float* out8, hipStream_t st) {
+  if (!q || !p || !n || !hp || !dims || !workspace || !out8) return SNX_E_ARG;
+  LossDims d;
+  int rc = make_dims(d, dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], hp);
+  if (rc) return rc;
+  LossWs w = carve((float*)workspace, d.B, d.Bp, d.k, d.V, d.nchunk);
+  const size_t lds1 = (size_t)(d.B + d.Bp) * (d.CH + 1) * 4;
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(d.nchunk), dim3(256), lds1, st, q, p, n, d, w);
+  SNX_CHECK_LAUNCH();
+  const size_t lds2 = (size_t)(d.B * (d.Bp + d.k) + d.B * d.k + d.B) * 4;
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), lds2, st, d, w, tpos, tneg, out8);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+extern "C" int snx_loss_bwd(const float* q, const float* p, const float* n, const float* gout, const float* hp,
+                            const int32_t* dims, void* workspace, float* dq, float* dp, float* dn, hipStream_t st) {
+  if (!q || !p || !n || !gout || !hp || !dims || !workspace || !dq || !dp || !dn) return SNX_E_ARG;
+  LossDims d;
+  int rc = make_dims(d, dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], hp);
+  if (rc) return rc;
+  LossWs w = carve((float*)workspace, d.B, d.Bp, d.k, d.V, d.nchunk);
+  const size_t lds = (size_t)(d.B + d.Bp) * (d.CH + 1) * 4;
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(d.nchunk), dim3(256), lds, st, q, p, n, gout, d, w, dq, dp, dn);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}

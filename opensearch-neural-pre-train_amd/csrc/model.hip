@@ -1,0 +1,309 @@
+// Native runtime of the SPLADE-ModernBERT encoder: owns the layer loop, the activation arena
+// plan and the bf16 weight cache, and drives the HIP kernels of this library on one stream.
+// One call = one `SPLADEModernBERT.forward` (ref:src/model/splade_modern.py:50-88 ->
+// transformers modeling_modernbert.py:434-478,522-550) or its complete backward.
+// No allocation, no host sync, caller-owned buffers, stream-ordered, graph-capturable.
+#include "common.h"
+#include "snx.h"
+
+namespace {
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Dims {
+  int V, H, I, L, heads, T, nseq;
+};
+
+// canonical parameter order (== state-dict order with the tied decoder weight listed once)
+struct PIdx {
+  int L;
+  int tok_emb() const { return 0; }
+  int emb_norm() const { return 1; }
+  int base(int l) const { return l == 0 ? 2 : 7 + 6 * (l - 1); }
+  int attn_norm(int l) const { return base(l); }                 // l >= 1 only
+  int wqkv(int l) const { return base(l) + (l == 0 ? 0 : 1); }
+  int wo(int l) const { return wqkv(l) + 1; }
+  int mlp_norm(int l) const { return wqkv(l) + 2; }
+  int wi(int l) const { return wqkv(l) + 3; }
+  int wo_mlp(int l) const { return wqkv(l) + 4; }
+  int tail() const { return 7 + 6 * (L - 1); }
+  int final_norm() const { return tail(); }
+  int head_dense() const { return tail() + 1; }
+  int head_norm() const { return tail() + 2; }
+  int dec_bias() const { return tail() + 3; }
+  int count() const { return tail() + 4; }
+};
+
+// bf16 weight cache: every matrix as stored ([out,in], for the forward NT GEMM) and transposed
+// ([in,out], for the dX NT GEMM); the embedding/decoder matrix only as stored.
+struct CachePlan {
+  size_t emb;
+  size_t wqkv[64], wqkv_t[64], wo[64], wo_t[64], wi[64], wi_t[64], wom[64], wom_t[64];
+  size_t dense, dense_t;
+  size_t total;
+};
+
+bool plan_cache(const snx_model_desc* d, CachePlan& c) {
+  if (d->layers > 64 || d->layers < 1) return false;
+  const size_t H = d->hidden, I = d->inter, V = d->vocab;
+  size_t off = 0;
+  auto take = [&](size_t elems) { size_t o = off; off = al(off + elems * 2); return o; };
+  c.emb = take(V * H);
+  for (int l = 0; l < d->layers; ++l) {
+    c.wqkv[l] = take(3 * H * H); c.wqkv_t[l] = take(3 * H * H);
+    c.wo[l] = take(H * H); c.wo_t[l] = take(H * H);
+    c.wi[l] = take(2 * I * H); c.wi_t[l] = take(2 * I * H);
+    c.wom[l] = take(H * I); c.wom_t[l] = take(H * I);
+  }
+  c.dense = take(H * H); c.dense_t = take(H * H);
+  c.total = off;
+  return true;
+}
+
+// activation arena written by forward and read by backward
+struct SavedPlan {
+  size_t h[129];                 // residual stream after embeddings / each sub-layer, fp32 [T,H]
+  size_t x_attn[64], x_mlp[64];  // LayerNorm outputs feeding Wqkv / Wi, bf16 [T,H]
+  size_t qkv[64];                // post-RoPE q,k and v, bf16 [T,3H]
+  size_t attn[64];               // attention output (input of attn.Wo), bf16 [T,H]
+  size_t lse[64];                // fp32 [heads,T]
+  size_t u[64];                  // Wi output [a|g], bf16 [T,2I]
+  size_t y[64];                  // GeGLU output (input of mlp.Wo), bf16 [T,I]
+  size_t xf, dd, hd;             // final-norm out, head.dense out (pre-GELU), head out: bf16 [T,H]
+  size_t keys;                   // u32 [nseq,V]
+  size_t rowpart;                // forward-only scratch of the SPLADE head
+  size_t total;
+};
+
+bool plan_saved(const snx_model_desc* d, long T, long nseq, bool save, SavedPlan& s) {
+  if (d->layers > 64 || d->layers < 1) return false;
+  const size_t H = d->hidden, I = d->inter, V = d->vocab, L = d->layers;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
+  if (save) {
+    for (size_t i = 0; i <= 2 * L; ++i) s.h[i] = take(T * H * 4);
+    for (size_t l = 0; l < L; ++l) {
+      s.x_attn[l] = take(T * H * 2); s.x_mlp[l] = take(T * H * 2);
+      s.qkv[l] = take(T * 3 * H * 2); s.attn[l] = take(T * H * 2);
+      s.lse[l] = take((size_t)d->heads * T * 4);
+      s.u[l] = take(T * 2 * I * 2); s.y[l] = take(T * I * 2);
+    }
+  } else {                       // inference: ping-pong the stream, reuse one set of layer buffers
+    const size_t h0 = take(T * H * 4), h1 = take(T * H * 4);
+    for (size_t i = 0; i <= 2 * L; ++i) s.h[i] = (i & 1) ? h1 : h0;
+    const size_t xa = take(T * H * 2), xm = take(T * H * 2), qkv = take(T * 3 * H * 2), at = take(T * H * 2);
+    const size_t ls = take((size_t)d->heads * T * 4), u = take(T * 2 * I * 2), y = take(T * I * 2);
+    for (size_t l = 0; l < L; ++l) {
+      s.x_attn[l] = xa; s.x_mlp[l] = xm; s.qkv[l] = qkv; s.attn[l] = at; s.lse[l] = ls; s.u[l] = u; s.y[l] = y;
+    }
+  }
+  s.xf = take(T * H * 2); s.dd = take(T * H * 2); s.hd = take(T * H * 2);
+  s.keys = take(nseq * V * 4);
+  s.rowpart = take(snx_splade_head_scratch_bytes((int)T, (int)V));
+  s.total = off;
+  return true;
+}
+
+struct BwdPlan {
+  size_t dh;        // fp32 [T,H]   gradient of the residual stream
+  size_t a, b;      // bf16 [T,H]
+  size_t c;         // bf16 [T,I]
+  size_t w;         // bf16 [T,max(3H,2I)]
+  size_t delta;     // fp32 [heads,T]
+  size_t total;
+};
+
+void plan_bwd(const snx_model_desc* d, long T, BwdPlan& p) {
+  const size_t H = d->hidden, I = d->inter;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
+  p.dh = take(T * H * 4);
+  p.a = take(T * H * 2); p.b = take(T * H * 2);
+  p.c = take(T * I * 2);
+  p.w = take(T * (3 * H > 2 * I ? 3 * H : 2 * I) * 2);
+  p.delta = take((size_t)d->heads * T * 4);
+  p.total = off;
+}
+
+bool desc_ok(const snx_model_desc* d) {
+  return d && d->vocab > 0 && d->hidden > 0 && d->hidden % 256 == 0 && d->hidden <= 1024 && d->inter > 0 &&
+         d->inter % 64 == 0 && d->layers >= 1 && d->layers <= 64 && d->heads > 0 && d->head_dim == 64 &&
+         d->heads * d->head_dim == d->hidden && d->global_every >= 1 && d->window >= 0;
+}
+
+__global__ void add_bf16_into_f32_kernel(float* __restrict__ dst, const bf16_t* __restrict__ src, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 a = *(f32x4*)(dst + i * 4);
+  const bf16x4 b = *(const bf16x4*)(src + i * 4);
+  a[0] += bf2f(b[0]); a[1] += bf2f(b[1]); a[2] += bf2f(b[2]); a[3] += bf2f(b[3]);
+  *(f32x4*)(dst + i * 4) = a;
+}
+
+#define RC(call)            \
+  do {                      \
+    int rc__ = (call);      \
+    if (rc__) return rc__;  \
+  } while (0)
+
+}  // namespace
+
+extern "C" int snx_version(void) { return 1; }
+
+extern "C" int32_t snx_param_count(const snx_model_desc* d) {
+  if (!desc_ok(d)) return -1;
+  PIdx p{d->layers};
+  return p.count();
+}
+
+extern "C" size_t snx_weight_cache_bytes(const snx_model_desc* d) {
+  CachePlan c;
+  if (!desc_ok(d) || !plan_cache(d, c)) return 0;
+  return c.total;
+}
+
+extern "C" int snx_weight_cache_refresh(const snx_model_desc* d, const void* const* params, void* cache,
+                                        hipStream_t st) {
+  CachePlan c;
+  if (!desc_ok(d) || !plan_cache(d, c)) return SNX_E_SHAPE;
+  if (!params || !cache) return SNX_E_ARG;
+  PIdx p{d->layers};
+  char* base = (char*)cache;
+  const int H = d->hidden, I = d->inter, V = d->vocab;
+  auto both = [&](int idx, size_t o, size_t ot, int R, int C) -> int {
+    RC(snx_cast_bf16((const float*)params[idx], base + o, (int64_t)R * C, st));
+    return snx_cast_transpose_bf16((const float*)params[idx], base + ot, R, C, st);
+  };
+  RC(snx_cast_bf16((const float*)params[p.tok_emb()], base + c.emb, (int64_t)V * H, st));
+  for (int l = 0; l < d->layers; ++l) {
+    RC(both(p.wqkv(l), c.wqkv[l], c.wqkv_t[l], 3 * H, H));
+    RC(both(p.wo(l), c.wo[l], c.wo_t[l], H, H));
+    RC(both(p.wi(l), c.wi[l], c.wi_t[l], 2 * I, H));
+    RC(both(p.wo_mlp(l), c.wom[l], c.wom_t[l], H, I));
+  }
+  RC(both(p.head_dense(), c.dense, c.dense_t, H, H));
+  return SNX_OK;
+}
+
+extern "C" size_t snx_model_workspace_bytes(const snx_model_desc* d, int32_t T, int32_t nseq, int32_t save_for_bwd) {
+  SavedPlan s;
+  if (!desc_ok(d) || T <= 0 || nseq <= 0 || !plan_saved(d, T, nseq, save_for_bwd != 0, s)) return 0;
+  return s.total;
+}
+
+extern "C" size_t snx_model_bwd_workspace_bytes(const snx_model_desc* d, int32_t T, int32_t nseq) {
+  (void)nseq;
+  if (!desc_ok(d) || T <= 0) return 0;
+  BwdPlan p;
+  plan_bwd(d, T, p);
+  return p.total;
+}
+
+extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* params, const void* wcache,
+                                 const int64_t* ids, const int64_t* mask, const int32_t* cu_seqlens,
+                                 const int32_t* pos, const float* rope_global, const float* rope_local, void* saved,
+                                 float* sparse, float* token_weights, void* reserved, int32_t T, int32_t nseq,
+                                 int32_t max_seqlen, int32_t flags, hipStream_t st) {
+  (void)reserved;
+  if (!desc_ok(d)) return SNX_E_SHAPE;
+  if (!params || !wcache || !ids || !mask || !cu_seqlens || !pos || !rope_global || !rope_local || !saved || !sparse ||
+      !token_weights || T <= 0 || nseq <= 0 || max_seqlen <= 0)
+    return SNX_E_ARG;
+  const bool save = (flags & SNX_FWD_SAVE_FOR_BACKWARD) != 0;
+  CachePlan c;
+  SavedPlan s;
+  if (!plan_cache(d, c) || !plan_saved(d, T, nseq, save, s)) return SNX_E_SHAPE;
+  PIdx p{d->layers};
+  const char* wc = (const char*)wcache;
+  char* sv = (char*)saved;
+  const int H = d->hidden, I = d->inter, V = d->vocab, L = d->layers;
+  auto F = [&](int idx) { return (const float*)params[idx]; };
+  auto hbuf = [&](int i) { return (float*)(sv + s.h[i]); };
+
+  RC(snx_embed_ln_fwd(ids, F(p.tok_emb()), F(p.emb_norm()), hbuf(0), sv + s.x_attn[0], T, H, d->ln_eps, st));
+  for (int l = 0; l < L; ++l) {
+    const bool global = (l % d->global_every) == 0;
+    if (l > 0) RC(snx_ln_fwd(hbuf(2 * l), F(p.attn_norm(l)), sv + s.x_attn[l], T, H, d->ln_eps, st));
+    RC(snx_gemm_nt_bf16(sv + s.x_attn[l], wc + c.wqkv[l], sv + s.qkv[l], T, 3 * H, H, st));
+    RC(snx_rope_inplace(sv + s.qkv[l], global ? rope_global : rope_local, pos, T, d->heads, 0, st));
+    RC(snx_attn_fwd(sv + s.qkv[l], cu_seqlens, mask, sv + s.attn[l], (float*)(sv + s.lse[l]), T, nseq, max_seqlen,
+                    d->heads, d->head_dim, global ? -1 : d->window, st));
+    RC(snx_gemm_nt_resid(sv + s.attn[l], wc + c.wo[l], hbuf(2 * l), hbuf(2 * l + 1), T, H, H, st));
+    RC(snx_ln_fwd(hbuf(2 * l + 1), F(p.mlp_norm(l)), sv + s.x_mlp[l], T, H, d->ln_eps, st));
+    RC(snx_gemm_nt_bf16(sv + s.x_mlp[l], wc + c.wi[l], sv + s.u[l], T, 2 * I, H, st));
+    RC(snx_geglu_fwd(sv + s.u[l], sv + s.y[l], T, I, st));
+    RC(snx_gemm_nt_resid(sv + s.y[l], wc + c.wom[l], hbuf(2 * l + 1), hbuf(2 * l + 2), T, H, I, st));
+  }
+  RC(snx_ln_fwd(hbuf(2 * L), F(p.final_norm()), sv + s.xf, T, H, d->ln_eps, st));
+  RC(snx_gemm_nt_bf16(sv + s.xf, wc + c.dense, sv + s.dd, T, H, H, st));
+  RC(snx_gelu_ln_fwd(sv + s.dd, F(p.head_norm()), sv + s.hd, T, H, d->ln_eps, st));
+  RC(snx_decoder_splade_fwd(sv + s.hd, wc + c.emb, F(p.dec_bias()), cu_seqlens, mask, sparse,
+                            (uint32_t*)(sv + s.keys), token_weights, sv + s.rowpart, T, nseq, max_seqlen, V, H, st));
+  return SNX_OK;
+}
+
+extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* params, void* const* grads,
+                                  const void* wcache, const int64_t* ids, const int64_t* mask,
+                                  const int32_t* cu_seqlens, const int32_t* pos, const float* rope_global,
+                                  const float* rope_local, const void* saved, const float* g_sparse, void* scratch,
+                                  int32_t T, int32_t nseq, int32_t max_seqlen, hipStream_t st) {
+  if (!desc_ok(d)) return SNX_E_SHAPE;
+  if (!params || !grads || !wcache || !ids || !mask || !cu_seqlens || !pos || !rope_global || !rope_local || !saved ||
+      !g_sparse || !scratch || T <= 0 || nseq <= 0 || max_seqlen <= 0)
+    return SNX_E_ARG;
+  CachePlan c;
+  SavedPlan s;
+  BwdPlan b;
+  if (!plan_cache(d, c) || !plan_saved(d, T, nseq, true, s)) return SNX_E_SHAPE;
+  plan_bwd(d, T, b);
+  PIdx p{d->layers};
+  const char* wc = (const char*)wcache;
+  const char* sv = (const char*)saved;
+  char* sc = (char*)scratch;
+  const int H = d->hidden, I = d->inter, V = d->vocab, L = d->layers;
+  auto F = [&](int idx) { return (const float*)params[idx]; };
+  auto G = [&](int idx) { return (float*)grads[idx]; };
+  auto hbuf = [&](int i) { return (const float*)(sv + s.h[i]); };
+  float* dh = (float*)(sc + b.dh);
+  char *A = sc + b.a, *Bb = sc + b.b, *Cc = sc + b.c, *Wd = sc + b.w;
+  const long n4 = (long)T * H / 4;
+
+  // SPLADE tail + decoder (sparse routed), head
+  RC(snx_splade_bwd(g_sparse, (const uint32_t*)(sv + s.keys), sv + s.hd, wc + c.emb, cu_seqlens, A, G(p.tok_emb()),
+                    G(p.dec_bias()), nullptr, T, nseq, max_seqlen, V, H, st));
+  RC(snx_gelu_ln_bwd(A, sv + s.dd, F(p.head_norm()), Bb, G(p.head_norm()), T, H, d->ln_eps, st));
+  RC(snx_gemm_tn_accum(Bb, sv + s.xf, G(p.head_dense()), T, H, H, st));
+  RC(snx_gemm_nt_bf16(Bb, wc + c.dense_t, A, T, H, H, st));
+  RC(snx_ln_bwd(A, hbuf(2 * L), F(p.final_norm()), dh, G(p.final_norm()), T, H, d->ln_eps, 1, st));
+
+  for (int l = L - 1; l >= 0; --l) {
+    const bool global = (l % d->global_every) == 0;
+    // ---- MLP:  h[2l+2] = h[2l+1] + Wo( gelu(a) * g ),  [a|g] = Wi( LN(h[2l+1]) )
+    RC(snx_cast_bf16(dh, A, (int64_t)T * H, st));                                  // grad of the bf16 branch output
+    RC(snx_gemm_tn_accum(A, sv + s.y[l], G(p.wo_mlp(l)), T, H, I, st));
+    RC(snx_gemm_nt_bf16(A, wc + c.wom_t[l], Cc, T, I, H, st));                     // dy [T,I]
+    RC(snx_geglu_bwd(sv + s.u[l], Cc, Wd, T, I, st));                              // du [T,2I]
+    RC(snx_gemm_tn_accum(Wd, sv + s.x_mlp[l], G(p.wi(l)), T, 2 * I, H, st));
+    RC(snx_gemm_nt_bf16(Wd, wc + c.wi_t[l], A, T, H, 2 * I, st));                  // dx [T,H]
+    RC(snx_ln_bwd(A, hbuf(2 * l + 1), F(p.mlp_norm(l)), dh, G(p.mlp_norm(l)), T, H, d->ln_eps, 0, st));
+    // ---- attention:  h[2l+1] = h[2l] + Wo( attn( rope( Wqkv( LN(h[2l]) ) ) ) )
+    RC(snx_cast_bf16(dh, A, (int64_t)T * H, st));
+    RC(snx_gemm_tn_accum(A, sv + s.attn[l], G(p.wo(l)), T, H, H, st));
+    RC(snx_gemm_nt_bf16(A, wc + c.wo_t[l], Bb, T, H, H, st));                      // d(attn out)
+    RC(snx_attn_bwd(sv + s.qkv[l], sv + s.attn[l], Bb, (const float*)(sv + s.lse[l]), cu_seqlens, mask,
+                    (float*)(sc + b.delta), Wd, T, nseq, max_seqlen, d->heads, d->head_dim,
+                    global ? -1 : d->window, st));
+    RC(snx_rope_inplace(Wd, global ? rope_global : rope_local, pos, T, d->heads, 1, st));
+    RC(snx_gemm_tn_accum(Wd, sv + s.x_attn[l], G(p.wqkv(l)), T, 3 * H, H, st));
+    RC(snx_gemm_nt_bf16(Wd, wc + c.wqkv_t[l], A, T, H, 3 * H, st));                // dx [T,H]
+    if (l > 0) {
+      RC(snx_ln_bwd(A, hbuf(2 * l), F(p.attn_norm(l)), dh, G(p.attn_norm(l)), T, H, d->ln_eps, 0, st));
+    } else {
+      hipLaunchKernelGGL(add_bf16_into_f32_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dh, (const bf16_t*)A, n4);
+      SNX_CHECK_LAUNCH();
+    }
+  }
+  RC(snx_embed_ln_bwd(dh, ids, F(p.tok_emb()), F(p.emb_norm()), G(p.tok_emb()), G(p.emb_norm()), T, H, d->ln_eps,
+                      d->pad_id, st));
+  return SNX_OK;
+}

@@ -148,3 +148,145 @@ extern "C" int snx_decoder_splade_fwd(const void* Hd, const void* W, const float
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }
+
+// ==========================================================================================
+// Backward of the fused decoder + SPLADE tail (row a7 of SURVEY.md §8).
+// Autograd in the reference materialises a dense [T, V] dlogits tensor that is zero except at one
+// sequence position per (b, v) (the arg-max row), then runs two dense 2*T*V*H GEMMs.  Here the
+// gradient is routed through the saved packed keys instead:
+//   c[b,v]   = bf16( g[b,v] * [x > 0] / (1 + x) ),  x = bf16 logit at the arg-max row s*(b,v)
+//   dW[v,:] += sum_b c[b,v] * Hd[row(b, s*), :]          (one wave per vocab row: gather + FMA)
+//   db[v]   += sum_b c[b,v]
+//   dHd[row(b,s), :] = sum_{v: s*(b,v) = s} c[b,v] * W[v,:]   (per-sequence LDS accumulation)
+// Entries with c == 0 (inactive vocabulary terms -- the vast majority once the model is
+// trained) are skipped, so the cost follows the activation sparsity.
+// ==========================================================================================
+__device__ __forceinline__ float splade_coef(float g, uint32_t key) {
+  const float x = bits_to_f32(key >> 16);
+  return x > 0.f ? rbf(g / (1.0f + x)) : 0.f;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void splade_bwd_dw_kernel(const float* __restrict__ g,
+                                                            const uint32_t* __restrict__ keys,
+                                                            const bf16_t* __restrict__ Hd,
+                                                            const int32_t* __restrict__ cu_seqlens,
+                                                            float* __restrict__ gradE, float* __restrict__ gradb,
+                                                            int nseq, int V, int H) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int v = wid; v < V; v += nw) {
+    f32x4 acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int b0 = 0; b0 < nseq; b0 += 64) {
+      const int b = b0 + lane;
+      float c = 0.f;
+      int trow = 0;
+      if (b < nseq) {
+        const uint32_t key = keys[(long)b * V + v];
+        c = splade_coef(g[(long)b * V + v], key);
+        trow = cu_seqlens[b] + (int)(0xFFFFu - (key & 0xFFFFu));
+      }
+      const unsigned long long live = __ballot(c != 0.f);
+      bsum += c;
+      unsigned long long m = live;
+      while (m) {
+        const int src = __builtin_ctzll(m);
+        m &= m - 1;
+        const float cb = __shfl(c, src, 64);
+        const int tb = __shfl(trow, src, 64);
+        const bf16_t* hrow = Hd + (long)tb * H;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const bf16x4 h4 = *(const bf16x4*)(hrow + (i * 64 + lane) * 4);
+          acc[i][0] += cb * bf2f(h4[0]);
+          acc[i][1] += cb * bf2f(h4[1]);
+          acc[i][2] += cb * bf2f(h4[2]);
+          acc[i][3] += cb * bf2f(h4[3]);
+        }
+      }
+    }
+    bsum = wave_sum(bsum);
+    float* dst = gradE + (long)v * H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f32x4* p = (f32x4*)(dst + (i * 64 + lane) * 4);
+      *p = *p + acc[i];
+    }
+    if (lane == 0) gradb[v] += bsum;
+  }
+}
+
+// One workgroup = (sequence, CW-column slice of H).  dH slice lives in LDS as fp32 [slen][CW].
+__global__ __launch_bounds__(512) void splade_bwd_dh_kernel(const float* __restrict__ g,
+                                                            const uint32_t* __restrict__ keys,
+                                                            const bf16_t* __restrict__ W,
+                                                            const int32_t* __restrict__ cu_seqlens,
+                                                            bf16_t* __restrict__ dHd, int V, int H, int CW,
+                                                            int max_rows) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int seq = blockIdx.y, c0 = blockIdx.x * CW;
+  const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = slen < max_rows ? slen : max_rows;
+  for (int i = threadIdx.x; i < rows * CW; i += 512) sm[i] = 0.f;
+  __syncthreads();
+  const float* gs = g + (long)seq * V;
+  const uint32_t* ks = keys + (long)seq * V;
+  const int per_lane = CW / 64;                        // 1, 2, 4 or 8 columns per lane
+  for (int v0 = wave * 64; v0 < V; v0 += 8 * 64) {
+    const int v = v0 + lane;
+    float c = 0.f;
+    int row = 0;
+    if (v < V) {
+      const uint32_t key = ks[v];
+      c = splade_coef(gs[v], key);
+      row = (int)(0xFFFFu - (key & 0xFFFFu));
+      if (row >= rows) c = 0.f;                        // cannot happen for a valid key; keeps LDS in bounds
+    }
+    unsigned long long m = __ballot(c != 0.f);
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1;
+      const float cb = __shfl(c, src, 64);
+      const int rb = __shfl(row, src, 64);
+      const bf16_t* wrow = W + (long)(v0 + src) * H + c0 + lane * per_lane;
+      float* drow = sm + rb * CW + lane * per_lane;
+      for (int e = 0; e < per_lane; ++e) atomicAdd(drow + e, cb * bf2f(wrow[e]));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < rows * CW; i += 512) {
+    const int r = i / CW, c = i % CW;
+    dHd[(long)(s0 + r) * H + c0 + c] = f2bf(sm[i]);
+  }
+}
+
+extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* Hd, const void* W,
+                              const int32_t* cu_seqlens, void* dHd, float* gradE, float* gradb, void* reserved,
+                              int32_t T, int32_t nseq, int32_t max_seqlen, int32_t V, int32_t H, hipStream_t st) {
+  (void)reserved;
+  if (!g || !keys || !Hd || !W || !cu_seqlens || !dHd || !gradE || !gradb) return SNX_E_ARG;
+  if (T <= 0 || nseq <= 0 || V <= 0 || max_seqlen <= 0 || H <= 0 || (H % 256) || H > 1024) return SNX_E_SHAPE;
+  const int blocks = 2048;
+  switch (H / 256) {
+    case 1: hipLaunchKernelGGL(splade_bwd_dw_kernel<1>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+    case 2: hipLaunchKernelGGL(splade_bwd_dw_kernel<2>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+    case 3: hipLaunchKernelGGL(splade_bwd_dw_kernel<3>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+    default: hipLaunchKernelGGL(splade_bwd_dw_kernel<4>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+  }
+  SNX_CHECK_LAUNCH();
+  // column-slice width: largest of {512,256,128,64} dividing H whose fp32 [max_seqlen][CW] slab fits 128 KiB
+  int CW = 512;
+  while (CW > 64 && ((size_t)max_seqlen * CW * 4 > 128 * 1024 || (H % CW) != 0)) CW >>= 1;
+  if ((size_t)max_seqlen * CW * 4 > 160 * 1024 - 1024 || (H % CW) != 0) return SNX_E_SHAPE;
+  const size_t lds = (size_t)max_seqlen * CW * 4;
+  hipFuncSetAttribute((const void*)splade_bwd_dh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(splade_bwd_dh_kernel, dim3(H / CW, nseq), dim3(512), lds, st, g, keys, (const bf16_t*)W,
+                     cu_seqlens, (bf16_t*)dHd, V, H, CW, max_seqlen);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}

@@ -39,16 +39,16 @@ SIGNATURES = {
     "snx_splade_head_scratch_bytes": (SZ, [I32, I32]),
     "snx_decoder_splade_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),
     "snx_splade_bwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),
-    "snx_loss_workspace_bytes": (SZ, [I32, I32, I32]),
-    "snx_loss_fwd": (I32, [P, P, P, P, P, P, P, P, I32, I32, I32, P]),
-    "snx_loss_bwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, P]),
-    "snx_model_workspace_bytes": (SZ, [P, I32, I32]),
+    "snx_loss_workspace_bytes": (SZ, [I32, I32, I32, I32]),
+    "snx_loss_fwd": (I32, [P, P, P, P, P, P, P, P, P, P]),
+    "snx_loss_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P]),
+    "snx_model_workspace_bytes": (SZ, [P, I32, I32, I32]),
     "snx_model_bwd_workspace_bytes": (SZ, [P, I32, I32]),
     "snx_weight_cache_bytes": (SZ, [P]),
     "snx_weight_cache_refresh": (I32, [P, P, P, P]),
     "snx_model_forward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P]),
     "snx_model_backward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P]),
-    "snx_adamw_clip_step": (I32, [P, P, P, P, P, I32, P, F32, F32, F32, F32, F32, F32, I32, P]),
+    "snx_param_count": (I32, [P]),
     "snx_version": (I32, []),
 }
 

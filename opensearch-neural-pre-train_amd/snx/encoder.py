@@ -1,0 +1,222 @@
+"""Host-side runtime that binds a set of ``nn.Parameter``s to the native encoder entry points
+(``snx_model_forward`` / ``snx_model_backward``) and exposes them to autograd.
+
+PyTorch here is plumbing only: device memory (caching allocator), the current stream, and the
+autograd graph boundary.  All arithmetic happens in libsnx.so."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import check, fn
+from .ops import _p, _stream, rope_table
+
+SNX_FWD_SAVE_FOR_BACKWARD = 1
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("vocab", C.c_int32), ("hidden", C.c_int32), ("inter", C.c_int32), ("layers", C.c_int32),
+                ("heads", C.c_int32), ("head_dim", C.c_int32), ("global_every", C.c_int32), ("window", C.c_int32),
+                ("pad_id", C.c_int32), ("reserved0", C.c_int32), ("ln_eps", C.c_float), ("reserved1", C.c_float)]
+
+
+@dataclass
+class EncoderGeometry:
+    """The architecture constants the kernels need (field names follow the HF config.json)."""
+    vocab_size: int = 50000
+    hidden_size: int = 768
+    intermediate_size: int = 1152
+    num_hidden_layers: int = 22
+    num_attention_heads: int = 12
+    global_attn_every_n_layers: int = 3
+    local_attention: int = 128
+    global_rope_theta: float = 160000.0
+    local_rope_theta: float = 10000.0
+    norm_eps: float = 1e-5
+    pad_token_id: int = 49999
+    max_position_embeddings: int = 16384
+
+    def desc(self) -> ModelDesc:
+        hd = self.hidden_size // self.num_attention_heads
+        return ModelDesc(self.vocab_size, self.hidden_size, self.intermediate_size, self.num_hidden_layers,
+                         self.num_attention_heads, hd, self.global_attn_every_n_layers, self.local_attention // 2,
+                         self.pad_token_id, 0, self.norm_eps, 0.0)
+
+    def check_supported(self):
+        hd = self.hidden_size // self.num_attention_heads
+        if hd != 64 or self.hidden_size % 256 or self.hidden_size > 1024 or self.intermediate_size % 64:
+            raise ValueError("snx kernels need head_dim == 64, hidden % 256 == 0 (<= 1024), intermediate % 64 == 0; "
+                             f"got hidden={self.hidden_size}, heads={self.num_attention_heads}, "
+                             f"intermediate={self.intermediate_size}")
+        if (2 * self.intermediate_size) % 128 or self.intermediate_size % 128 or self.hidden_size % 128:
+            raise ValueError("weight-gradient GEMM needs hidden, intermediate multiples of 128")
+
+
+class EncoderRuntime:
+    """Binds parameters (canonical order, see include/snx.h) to the native forward/backward."""
+
+    def __init__(self, geom: EncoderGeometry, params: Sequence[torch.nn.Parameter]):
+        geom.check_supported()
+        self.geom = geom
+        self.params = list(params)
+        self._desc = geom.desc()
+        n = fn("snx_param_count")(C.byref(self._desc))
+        if n != len(self.params):
+            raise ValueError(f"expected {n} parameter tensors in canonical order, got {len(self.params)}")
+        self._ptr_key = None
+        self._ptr_arr = None
+        self._wcache: Optional[torch.Tensor] = None
+        self._wcache_key = None
+        self._rope: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._seq_cache: Dict[Tuple[int, int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.direct_grads = False
+        self.flat_grad: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _device(self):
+        d = self.params[0].device
+        if d.type != "cuda":
+            raise RuntimeError("SPLADEModernBERT (snx backend) runs on an AMD GPU only: move the module to "
+                               "cuda:<local_rank>; there is no CPU fallback for the product path")
+        return d
+
+    def _param_ptrs(self):
+        key = tuple(p.data_ptr() for p in self.params)
+        if key != self._ptr_key:
+            for p in self.params:
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise ValueError("parameters must be contiguous fp32 (master weights)")
+            self._ptr_arr = (C.c_void_p * len(key))(*key)
+            self._ptr_key = key
+            self._wcache_key = None
+        return self._ptr_arr
+
+    def _weights(self):
+        """bf16 weight cache, refreshed when any parameter changed (optimizer step / load)."""
+        ptrs = self._param_ptrs()
+        dev = self._device()
+        key = tuple(p._version for p in self.params)
+        if self._wcache is None or self._wcache.device != dev:
+            nbytes = fn("snx_weight_cache_bytes")(C.byref(self._desc))
+            self._wcache = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._wcache_key = None
+        if key != self._wcache_key:
+            check(fn("snx_weight_cache_refresh")(C.byref(self._desc), ptrs, _p(self._wcache), _stream()),
+                  "snx_weight_cache_refresh")
+            self._wcache_key = key
+        return self._wcache
+
+    def _rope_tables(self, max_pos: int, dev):
+        k = (max_pos, str(dev))
+        if k not in self._rope:
+            self._rope[k] = (rope_table(max_pos, 64, self.geom.global_rope_theta, dev),
+                             rope_table(max_pos, 64, self.geom.local_rope_theta, dev))
+        return self._rope[k]
+
+    def _seq_layout(self, B: int, S: int, dev):
+        k = (B, S, str(dev))
+        if k not in self._seq_cache:
+            cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
+            pos = torch.arange(S, dtype=torch.int32).repeat(B).to(dev)
+            self._seq_cache[k] = (cu, pos)
+        return self._seq_cache[k]
+
+    # ------------------------------------------------------------------ gradients
+    def enable_direct_grads(self, on: bool = True):
+        """Accumulate parameter gradients straight into one flat fp32 buffer whose slices ARE the
+        ``.grad`` tensors (no per-call gradient tensors, one buffer for the RCCL all-reduce).
+        Autograd then sees no parameter gradients from the encoder: not for torch DDP."""
+        self.direct_grads = on
+        if on:
+            dev = self._device()
+            total = sum(p.numel() for p in self.params)
+            if self.flat_grad is None or self.flat_grad.device != dev:
+                self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+            off = 0
+            for p in self.params:
+                p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+                off += p.numel()
+
+    def zero_grads(self):
+        if self.flat_grad is not None:
+            self.flat_grad.zero_()
+
+    def _grad_ptrs(self, tensors):
+        return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward_impl(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool):
+        dev = self._device()
+        if input_ids.dim() != 2 or attention_mask.shape != input_ids.shape:
+            raise ValueError("input_ids and attention_mask must both be [batch, seq_len]")
+        if input_ids.device != dev or attention_mask.device != dev:
+            raise ValueError("inputs must live on the module's device")
+        B, S = input_ids.shape
+        if S > self.geom.max_position_embeddings or S > 65535:
+            raise ValueError("sequence too long")
+        ids = input_ids.to(torch.int64).contiguous().view(-1)
+        mask = attention_mask.to(torch.int64).contiguous().view(-1)
+        T = B * S
+        cu, pos = self._seq_layout(B, S, dev)
+        rg, rl = self._rope_tables(max(S, 64), dev)
+        wc = self._weights()
+        nbytes = fn("snx_model_workspace_bytes")(C.byref(self._desc), T, B, int(save))
+        saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        sparse = torch.empty((B, self.geom.vocab_size), dtype=torch.float32, device=dev)
+        tw = torch.empty((B, S), dtype=torch.float32, device=dev)
+        check(fn("snx_model_forward")(C.byref(self._desc), self._param_ptrs(), _p(wc), _p(ids), _p(mask), _p(cu),
+                                      _p(pos), _p(rg), _p(rl), _p(saved), _p(sparse), _p(tw), None, T, B, S,
+                                      SNX_FWD_SAVE_FOR_BACKWARD if save else 0, _stream()), "snx_model_forward")
+        aux = (ids, mask, cu, pos, rg, rl, T, B, S)
+        return sparse, tw, saved, aux
+
+    def backward_impl(self, saved: torch.Tensor, aux, g_sparse: torch.Tensor):
+        ids, mask, cu, pos, rg, rl, T, B, S = aux
+        dev = self._device()
+        if g_sparse.shape != (B, self.geom.vocab_size):
+            raise ValueError("bad gradient shape")
+        g = g_sparse.to(torch.float32).contiguous()
+        if self.direct_grads:
+            grads = [p.grad for p in self.params]
+            ret = None
+        else:
+            total = sum(p.numel() for p in self.params)
+            flat = torch.zeros(total, dtype=torch.float32, device=dev)
+            grads, off = [], 0
+            for p in self.params:
+                grads.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            ret = grads
+        nbytes = fn("snx_model_bwd_workspace_bytes")(C.byref(self._desc), T, B)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(fn("snx_model_backward")(C.byref(self._desc), self._param_ptrs(), self._grad_ptrs(grads),
+                                       _p(self._weights()), _p(ids), _p(mask), _p(cu), _p(pos), _p(rg), _p(rl),
+                                       _p(saved), _p(g), _p(scratch), T, B, S, _stream()), "snx_model_backward")
+        return ret
+
+    def __call__(self, input_ids, attention_mask):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.params):
+            return _SpladeEncodeFn.apply(self, input_ids, attention_mask, *self.params)
+        sparse, tw, _, _ = self.forward_impl(input_ids, attention_mask, save=False)
+        return sparse, tw
+
+
+class _SpladeEncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rt: EncoderRuntime, input_ids, attention_mask, *params):
+        sparse, tw, saved, aux = rt.forward_impl(input_ids, attention_mask, save=True)
+        ctx.rt, ctx.saved_arena, ctx.aux = rt, saved, aux
+        ctx.mark_non_differentiable(tw)
+        return sparse, tw
+
+    @staticmethod
+    def backward(ctx, g_sparse, _g_tw):
+        rt = ctx.rt
+        grads = rt.backward_impl(ctx.saved_arena, ctx.aux, g_sparse)
+        ctx.saved_arena = None
+        if grads is None:
+            return (None, None, None) + tuple(None for _ in rt.params)
+        return (None, None, None) + tuple(grads)

@@ -1,0 +1,282 @@
+"""End-to-end parity of the HIP path behind the reference API (SPLADEModernBERT + SPLADELossV33)
+against the CPU oracle and the committed golden vectors.  Needs a real MI355X: pytest -m gpu.
+
+Tolerance protocol:
+  * loss kernels, fp32 operands ............ vs golden g4 (reference outputs): rel 2e-5
+  * bf16 production path vs the oracle in emulated-bf16 mode (same cast points): sparse values
+    max-abs / mean-abs bounds below, top-k indices exact where the oracle's rank gap > 2x the
+    value error; loss terms rel 5e-3; per-tensor gradient cosine >= 0.999 and rel-L2 <= 3e-2
+  * bf16 production path vs the reference fp32 golden (g3, full size): reported, loose bound
+    (torch's own CPU bf16 autocast vs fp32 gives max 6.9e-3 / mean 1.4e-3 on this model)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+OUT = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _report(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_report.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **obj}) + "\n")
+
+
+def _small_cfg():
+    from oracle import splade_oracle as O
+    return O.EncoderConfig(vocab_size=1000, hidden_size=256, intermediate_size=384, num_hidden_layers=4,
+                           num_attention_heads=4, local_attention=16, pad_token_id=999)
+
+
+def _build_model(cfg, params, dev):
+    from src.model.splade_modern import SPLADEModernBERT
+    geom = dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                global_attn_every_n_layers=cfg.global_attn_every_n_layers, local_attention=cfg.local_attention,
+                global_rope_theta=cfg.global_rope_theta, local_rope_theta=cfg.local_rope_theta,
+                norm_eps=cfg.norm_eps, pad_token_id=cfg.pad_token_id)
+    m = SPLADEModernBERT(config=geom)
+    sd = {k: v.clone() for k, v in params.items()}
+    sd["model.decoder.weight"] = sd["model.model.embeddings.tok_embeddings.weight"]
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev)
+
+
+def test_state_dict_contract(dev):
+    from oracle import splade_oracle as O
+    cfg = _small_cfg()
+    m = _build_model(cfg, O.init_params(cfg, 1), dev)
+    keys = list(m.state_dict().keys())
+    assert len(keys) == len(O.param_names(cfg)) + 1 and "model.decoder.weight" in keys
+    assert [n for n, _ in m.named_parameters()] == O.param_names(cfg)
+    assert m.state_dict()["model.decoder.weight"].data_ptr() == m.state_dict()["model.model.embeddings.tok_embeddings.weight"].data_ptr()
+    assert m.vocab_size == 1000 and m.hidden_size == 256
+
+
+def _grad_stats(got, ref):
+    g, r = got.double().flatten(), ref.double().flatten()
+    cos = float((g @ r) / (g.norm() * r.norm() + 1e-30))
+    rel = float((g - r).norm() / (r.norm() + 1e-30))
+    return cos, rel
+
+
+@pytest.mark.parametrize("k,margin,Sq,Sd,cos_min,rel_max", [(1, 0.0, 8, 12, 0.999, 3e-2), (2, 0.05, 8, 12, 0.999, 3e-2),
+                                                            (1, 0.0, 40, 150, 0.98, 0.2), (2, 0.05, 40, 150, 0.98, 0.2)])
+def test_small_model_forward_backward_vs_oracle(dev, k, margin, Sq, Sd, cos_min, rel_max):
+    """Gradient tolerance: the max-pool routes each (b, v) gradient to ONE sequence position; bf16
+    logits tie or nearly tie often, so a 1-ulp accumulation-order flip re-routes that entry.  With
+    short sequences flips are rare and the tight bound (cos >= 0.999, rel-L2 <= 3e-2) holds; at
+    q40/d150 the oracle's OWN bf16-vs-fp32 gradients agree only to cos ~0.99 / rel ~0.14 (measured,
+    see DESIGN.md), so that case is held to cos >= 0.98 / rel <= 0.2 and the numbers are reported."""
+    from oracle import splade_oracle as O
+    from src.model.losses import SPLADELossV33
+    cfg = _small_cfg()
+    params = O.perturb_params(O.init_params(cfg, seed=3), seed=4, scale=2.0, bias_mean=-0.1)
+    gen = torch.Generator().manual_seed(100 + k)
+    b = O.synth_batch(6, Sq, Sd, cfg, gen, k=k, ragged=True, teacher=margin > 0)
+    lc = O.LossConfig(lambda_q=0.01, lambda_d=0.003, temperature=20.0, flops_warmup_steps=50,
+                      lambda_initial_ratio=0.1, lambda_margin_mse=margin)
+    step = 20
+    # oracle, emulated-bf16 mode
+    leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    oq, oqt = O.splade_forward(leaves, cfg, b["query_input_ids"], b["query_attention_mask"], "bf16")
+    op, opt = O.splade_forward(leaves, cfg, b["positive_input_ids"], b["positive_attention_mask"], "bf16")
+    on, ont = O.splade_forward(leaves, cfg, b["negative_input_ids"], b["negative_attention_mask"], "bf16")
+    on3 = on.view(6, k, -1) if k > 1 else on
+    oloss, od = O.loss_v33(lc, oq, op, on3, step, b.get("teacher_pos_scores"), b.get("teacher_neg_scores"), "bf16")
+    oloss.backward()
+    # HIP path through the reference API
+    model = _build_model(cfg, params, dev)
+    loss_fn = SPLADELossV33(lambda_q=lc.lambda_q, lambda_d=lc.lambda_d, temperature=lc.temperature,
+                            flops_warmup_steps=lc.flops_warmup_steps, lambda_initial_ratio=lc.lambda_initial_ratio,
+                            lambda_margin_mse=margin).to(dev)
+    D = lambda t: t.to(dev) if torch.is_tensor(t) else t   # noqa: E731
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        q, qt = model(D(b["query_input_ids"]), D(b["query_attention_mask"]))
+        p, pt = model(D(b["positive_input_ids"]), D(b["positive_attention_mask"]))
+        n, nt = model(D(b["negative_input_ids"]), D(b["negative_attention_mask"]))
+        n3 = n.view(6, k, -1) if k > 1 else n
+        loss, d = loss_fn(anchor_repr=q, positive_repr=p, negative_repr=n3, global_step=step,
+                          teacher_pos_scores=D(b.get("teacher_pos_scores")),
+                          teacher_neg_scores=D(b.get("teacher_neg_scores")))
+    loss.backward()
+    rep = {}
+    for tag, got, ref in (("q", q, oq), ("p", p, op), ("n", n, on), ("qt", qt, oqt), ("pt", pt, opt)):
+        diff = (got.detach().cpu() - ref.detach()).abs()
+        rep[tag] = {"max": float(diff.max()), "mean": float(diff.mean()), "scale": float(ref.abs().max())}
+        assert torch.isfinite(got).all()
+        assert diff.max().item() < 0.03 * max(1.0, rep[tag]["scale"]), (tag, rep[tag])
+        assert diff.mean().item() < 2e-3, (tag, rep[tag])
+    # padded positions are exactly zero
+    assert (pt.detach().cpu()[b["positive_attention_mask"] == 0] == 0).all()
+    # top-k indices exact where the oracle gap allows
+    ov, oi = torch.topk(op.detach(), 32, dim=-1)
+    gv, gi = torch.topk(p.detach().cpu(), 32, dim=-1)
+    gap = (ov[:, :-1] - ov[:, 1:]) > 2 * max(rep["p"]["max"], 1e-6)
+    ok = gap[:, 1:] & gap[:, :-1]
+    assert torch.equal(oi[:, 1:-1][ok], gi[:, 1:-1][ok])
+    rep["topk_checked_frac"] = float(ok.float().mean())
+    rep["loss"] = {"got": float(loss), "ref": float(oloss)}
+    assert float(loss) == pytest.approx(float(oloss), rel=5e-3)
+    for key in ("infonce", "flops_q", "flops_d", "flops_neg", "margin_mse", "nonzero_q", "nonzero_d"):
+        assert float(d[key]) == pytest.approx(od[key], rel=1e-2, abs=1e-4), key
+    worst = (1.0, 0.0, "")
+    for name, prm in model.named_parameters():
+        cos, rel = _grad_stats(prm.grad.cpu(), leaves[name].grad)
+        rep.setdefault("grads", {})[name] = [cos, rel]
+        if cos < worst[0]:
+            worst = (cos, rel, name)
+    rep["worst_grad"] = worst
+    _report(f"small_fwd_bwd_k{k}_q{Sq}_d{Sd}", rep)
+    bad = {n_: v for n_, v in rep["grads"].items() if v[0] < cos_min or v[1] > rel_max}
+    assert not bad, bad
+
+
+def test_loss_kernels_vs_golden_g4(dev):
+    """fp32-operand loss kernels vs the reference's own outputs (24 cases: B in {4,64}, k in
+    {1,4,7}, warm-up steps, MarginMSE, lambda_neg fallback)."""
+    from src.model.losses import SPLADELossV33
+    z = np.load(os.path.join(G, "g4_loss_vectors.npz"))
+    cases = json.load(open(os.path.join(G, "g4_loss_vectors.json")))
+    for c in cases:
+        pre = f"c{c['id']}::"
+        a, p, n = (torch.from_numpy(z[pre + x]).to(dev).requires_grad_(True) for x in "apn")
+        lf = SPLADELossV33(**c["loss_kwargs"]).to(dev)
+        loss, d = lf(anchor_repr=a, positive_repr=p, negative_repr=n, global_step=c["step"],
+                     teacher_pos_scores=torch.from_numpy(z[pre + "tp"]).to(dev),
+                     teacher_neg_scores=torch.from_numpy(z[pre + "tn"]).to(dev))
+        assert float(loss) == pytest.approx(c["loss"], rel=2e-5), c["id"]
+        for key, v in c["loss_dict"].items():
+            assert float(d[key]) == pytest.approx(v, rel=2e-5, abs=1e-6), (c["id"], key)
+        loss.backward()
+        for x, t in zip("apn", (a, p, n)):
+            np.testing.assert_allclose(t.grad.cpu().numpy(), z[pre + "d" + x], atol=2e-6, rtol=5e-4)
+        assert lf.get_avg_nonzero()[0] == pytest.approx(c["avg_nonzero"][0], rel=1e-5)
+
+
+def test_loss_cross_rank_identity(dev):
+    """config-4 extension: anchors of `rank` against all-gathered positives == the oracle identity."""
+    from oracle import splade_oracle as O
+    from snx.loss import splade_loss
+    g = torch.Generator().manual_seed(5)
+    B, W, V, rank = 8, 4, 300, 2
+    a = torch.relu(torch.rand(B, V, generator=g) - 0.5)
+    pall = torch.relu(torch.rand(W * B, V, generator=g) - 0.5)
+    n = torch.relu(torch.rand(B, V, generator=g) - 0.5)
+    al, pl, nl = (t.clone().requires_grad_(True) for t in (a, pall, n))
+    ref = O.cross_rank_infonce(al, pl, nl, rank, 2.0)
+    ref.backward()
+    ad, pd, nd = (t.to(dev).requires_grad_(True) for t in (a, pall, n))
+    loss, sc = splade_loss(ad, pd, nd, (2.0, 0.0, 0.0, 0.0, 0.0), 1, label_off=rank * B)
+    loss.backward()
+    assert float(sc[1]) == pytest.approx(float(ref), rel=1e-5)
+    for got, r in ((ad, al), (pd, pl), (nd, nl)):
+        np.testing.assert_allclose(got.grad.cpu().numpy(), r.grad.numpy(), atol=1e-7, rtol=1e-4)
+
+
+@pytest.fixture(scope="module")
+def full_setup(dev):
+    from oracle import splade_oracle as O
+    cfg = O.EncoderConfig()
+    params = O.perturb_params(O.init_params(cfg, seed=42), seed=7, bias_mean=-0.2)
+    return cfg, params, _build_model(cfg, params, dev)
+
+
+def test_full_size_vs_reference_golden_g3(dev, full_setup):
+    """149M model, B=4, q64/d256 ragged: HIP bf16 path vs the REFERENCE's fp32 outputs (g3)."""
+    from src.model.losses import SPLADELossV33
+    cfg, params, model = full_setup
+    z = np.load(os.path.join(G, "g3_full_fwd_bwd.npz"))
+    meta = json.load(open(os.path.join(G, "g3_full_fwd_bwd.json")))
+    b = {k[4:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("in::")}
+    rep = {}
+    outs = {}
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        for tag, pre in (("q", "query"), ("p", "positive"), ("n", "negative")):
+            sr, tw = model(b[pre + "_input_ids"], b[pre + "_attention_mask"])
+            outs[tag] = sr
+            ref_full = torch.from_numpy(z[f"out::{tag}_full"].astype(np.float32))
+            diff = (sr.detach().cpu() - ref_full).abs()
+            tv, ti = torch.topk(sr.detach().cpu(), 256, dim=-1)
+            rv, ri = torch.from_numpy(z[f"out::{tag}_topv"]), torch.from_numpy(z[f"out::{tag}_topi"])
+            overlap = np.mean([len(set(ti[r, :50].tolist()) & set(ri[r, :50].tolist())) / 50 for r in range(ti.shape[0])])
+            tdiff = (tv - rv).abs()
+            twd = (tw.detach().cpu().reshape(-1) - torch.from_numpy(z[f"out::{tag}_tw"]).reshape(-1)).abs()
+            rep[tag] = {"full_max": float(diff.max()), "full_mean": float(diff.mean()), "top256_val_max": float(tdiff.max()),
+                        "top50_overlap": float(overlap), "tw_max": float(twd.max()), "scale": float(rv.max())}
+            assert torch.isfinite(sr).all()
+            assert diff.max().item() < 0.05 and diff.mean().item() < 4e-3, rep[tag]
+            assert overlap > 0.85, rep[tag]
+        lf = SPLADELossV33(**meta["loss_kwargs"]).to(dev)
+        loss, d = lf(anchor_repr=outs["q"], positive_repr=outs["p"], negative_repr=outs["n"],
+                     global_step=meta["global_step"])
+    rep["loss"] = {"got": float(loss), "ref": meta["loss"], "infonce": float(d["infonce"]),
+                   "ref_infonce": meta["loss_dict"]["infonce"]}
+    for key in ("flops_q", "flops_d", "flops_neg"):
+        assert float(d[key]) == pytest.approx(meta["loss_dict"][key], rel=1e-2), key
+    loss.backward()
+    norms = dict(zip(meta["grad_names"], meta["grad_norms"]))
+    gn = {}
+    for name, prm in model.named_parameters():
+        gn[name] = float(prm.grad.double().norm())
+    rep["grad_norm_ratio_minmax"] = [min(gn[n] / max(norms[n], 1e-30) for n in gn),
+                                     max(gn[n] / max(norms[n], 1e-30) for n in gn)]
+    pg = dict(model.named_parameters())
+    probe = {}
+    for key in z.files:
+        if key.startswith("gprobe::model"):
+            g = pg[key[8:]].grad
+            got = (g[:8, :64] if g.dim() == 2 else g[:512]).cpu()
+            probe[key[8:]] = _grad_stats(got, torch.from_numpy(z[key]))
+    rep["grad_probe_cos_rel"] = probe
+    _report("full_vs_reference_fp32_g3", rep)
+    for n_, (cos, rel) in probe.items():   # bf16 path vs fp32 reference, saturated InfoNCE: noise floor ~0.98
+        assert cos > 0.95, (n_, cos, rel)
+    model.zero_grad(set_to_none=True)
+
+
+def test_full_size_vs_oracle_bf16(dev, full_setup):
+    """Same inputs, HIP vs the oracle with the SAME bf16 cast points (tight)."""
+    from oracle import splade_oracle as O
+    cfg, params, model = full_setup
+    gen = torch.Generator().manual_seed(777)
+    ids, mask = O.synth_ids(2, 256, cfg, gen, ragged=True)
+    with torch.no_grad():
+        ref, ref_tw = O.splade_forward(params, cfg, ids, mask, "bf16")
+        got, got_tw = model(ids.to(dev), mask.to(dev))
+    diff = (got.cpu() - ref).abs()
+    rep = {"max": float(diff.max()), "mean": float(diff.mean()), "p999": float(diff.flatten().kthvalue(int(diff.numel() * 0.999)).values)}
+    ov, oi = torch.topk(ref, 64, dim=-1)
+    gv, gi = torch.topk(got.cpu(), 64, dim=-1)
+    gap = (ov[:, :-1] - ov[:, 1:]) > 2 * max(rep["max"], 1e-6)
+    ok = gap[:, 1:] & gap[:, :-1]
+    rep["topk_exact_where_checked"] = bool(torch.equal(oi[:, 1:-1][ok], gi[:, 1:-1][ok]))
+    rep["topk_checked_frac"] = float(ok.float().mean())
+    rep["top10_equal"] = bool(torch.equal(oi[:, :10], gi[:, :10]))
+    _report("full_vs_oracle_bf16", rep)
+    assert diff.max().item() < 1e-2 and diff.mean().item() < 1e-3, rep
+    assert rep["topk_exact_where_checked"]
+    assert (got_tw.cpu()[mask == 0] == 0).all()
+
+
+def test_inference_matches_training_forward(dev, full_setup):
+    from oracle import splade_oracle as O
+    cfg, params, model = full_setup
+    gen = torch.Generator().manual_seed(9)
+    ids, mask = O.synth_ids(3, 64, cfg, gen, ragged=True)
+    with torch.no_grad():
+        a, _ = model(ids.to(dev), mask.to(dev))
+    b, _ = model(ids.to(dev), mask.to(dev))
+    assert torch.equal(a, b.detach())
+    assert torch.equal(model.encode(ids.to(dev), mask.to(dev)).detach(), a)

@@ -279,3 +279,104 @@ def test_decoder_splade_fwd(dev, B, S, V, K):
     first = torch.where(same.any(1), same.float().argmax(1), torch.zeros_like(row))
     agree = (first == row) | ~pos | ((at_row - val).abs() > 0)
     assert agree.float().mean().item() > 0.999
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 768, 256), (4096, 2304, 768), (777, 768, 1152), (200, 256, 384)])
+def test_gemm_tn_accum(dev, M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + K)
+    dy = (torch.randn(M, N, generator=g) * 0.1).to(dev).to(BF16)
+    x = torch.randn(M, K, generator=g).to(dev).to(BF16)
+    dw0 = torch.randn(N, K, generator=g).to(dev)
+    dw = dw0.clone()
+    ops.gemm_tn_accum(dy, x, dw)
+    ref = dw0 + dy.float().t() @ x.float()
+    err = (dw - ref).abs().max().item()
+    assert err < 1e-3 * max(1.0, ref.abs().max().item()), err
+
+
+def test_gemm_tn_layout(dev):
+    """dY = shifted identity pattern: dW[n, :] must equal X[row(n), :] (catches n/k swaps)."""
+    ops = _ops()
+    M, N, K = 128, 128, 256
+    dy = torch.zeros(M, N, device=dev)
+    perm = (torch.arange(N, device=dev) * 37 + 5) % M
+    dy[perm, torch.arange(N, device=dev)] = 1.0
+    x = ((torch.arange(M * K, device=dev, dtype=torch.float32).reshape(M, K) % 199) - 99.0).to(BF16)
+    dw = torch.zeros(N, K, device=dev)
+    ops.gemm_tn_accum(dy.to(BF16), x, dw)
+    assert torch.equal(dw, x.float()[perm])
+
+
+@pytest.mark.parametrize("S,window", [(64, -1), (256, 64), (200, 8), (130, -1)])
+def test_attention_bwd(dev, S, window):
+    from oracle import splade_oracle as O
+    ops = _ops()
+    B, heads = 3, 2
+    T = B * S
+    lens, mask = _ragged(B, S, 3 * S + window)
+    g = torch.Generator().manual_seed(21)
+    qkv = (torch.randn(T, 3 * heads * 64, generator=g) * 1.2).to(BF16)
+    dout = (torch.randn(T, heads * 64, generator=g) * 0.5).to(BF16)
+    dout[mask.reshape(-1) == 0] = 0          # padded rows never receive gradient
+    cu = torch.arange(B + 1, dtype=torch.int32) * S
+    qd, cud, md = qkv.to(dev), cu.to(dev), mask.reshape(-1).to(dev)
+    out, lse = ops.attn_fwd(qd, cud, md, S, heads, window)
+    dqkv = ops.attn_bwd(qd, out, dout.to(dev), lse, cud, md, S, heads, window)
+    x = qkv.float().view(B, S, 3, heads, 64).clone().requires_grad_(True)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    vis = O.attention_bias(mask, None if window < 0 else window)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    s = s.masked_fill(~vis, float("-inf"))
+    rowok = vis.any(-1, keepdim=True)
+    p = torch.where(rowok, torch.softmax(s.masked_fill(~rowok, 0.0), dim=-1), torch.zeros_like(s))
+    o = (p @ v).transpose(1, 2).reshape(T, heads * 64)
+    (o * dout.float()).sum().backward()
+    ref = x.grad.view(T, 3 * heads * 64)
+    valid = mask.reshape(-1).bool()
+    got = dqkv.cpu().float()
+    for name, sl in (("dq", slice(0, heads * 64)), ("dk", slice(heads * 64, 2 * heads * 64)), ("dv", slice(2 * heads * 64, None))):
+        gg, rr = got[valid][:, sl].double().flatten(), ref[valid][:, sl].double().flatten()
+        cos = float(gg @ rr / (gg.norm() * rr.norm()))
+        rel = float((gg - rr).norm() / rr.norm())
+        assert cos > 0.9995 and rel < 2e-2, (name, cos, rel)
+    assert torch.isfinite(got).all()
+    if (~valid).any():   # keys at padded positions get no gradient
+        assert got[~valid][:, heads * 64:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("B,S,V,H", [(3, 64, 1000, 256), (4, 256, 3000, 768), (2, 200, 640, 256)])
+def test_splade_bwd(dev, B, S, V, H):
+    ops = _ops()
+    from snx._lib import fn, check
+    from snx.ops import _p, _stream
+    T = B * S
+    lens, mask = _ragged(B, S, V + 1)
+    g = torch.Generator().manual_seed(23)
+    hd = torch.randn(T, H, generator=g).to(BF16)
+    W = (torch.randn(V, H, generator=g) * 0.05).to(BF16)
+    bias = torch.randn(V, generator=g) * 0.3
+    gs = torch.randn(B, V, generator=g)
+    gs[:, ::7] = 0.0
+    cu = torch.arange(B + 1, dtype=torch.int32) * S
+    hdd, Wd, bd, cud, md = hd.to(dev), W.to(dev), bias.to(dev), cu.to(dev), mask.reshape(-1).to(dev)
+    sp, keys, tw = ops.decoder_splade_fwd(hdd, Wd, bd, cud, md, S)
+    dHd = torch.full((T, H), float("nan"), dtype=BF16, device=dev)
+    gE0 = torch.randn(V, H, generator=g).to(dev)
+    gb0 = torch.randn(V, generator=g).to(dev)
+    gE, gb = gE0.clone(), gb0.clone()
+    check(fn("snx_splade_bwd")(_p(gs.to(dev)), _p(keys), _p(hdd), _p(Wd), _p(cud), _p(dHd), _p(gE), _p(gb), None,
+                               T, B, S, V, H, _stream()), "snx_splade_bwd")
+    # dense reference through autograd on the bf16 logits
+    hl = hdd.float().requires_grad_(True)
+    Wl = Wd.float().requires_grad_(True)
+    bl = bd.to(BF16).float().requires_grad_(True)
+    logits = (hl @ Wl.t() + bl).to(BF16)
+    sc = torch.log1p(torch.relu(logits).float()).view(B, S, V) * md.view(B, S, 1).float()
+    sc.max(dim=1).values.backward(gs.to(dev))
+    assert torch.isfinite(dHd.float()).all()
+    for name, got, ref in (("dHd", dHd.float(), hl.grad), ("dW", gE - gE0, Wl.grad), ("db", gb - gb0, bl.grad)):
+        gg, rr = got.double().flatten(), ref.double().flatten()
+        cos = float(gg @ rr / (gg.norm() * rr.norm() + 1e-30))
+        rel = float((gg - rr).norm() / (rr.norm() + 1e-30))
+        assert cos > 0.999 and rel < 2e-2, (name, cos, rel)
