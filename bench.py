@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Benchmark of the SPLADE-ModernBERT data-parallel training step on MI355X.
+
+    python bench.py --gpus 1 --steps 16 --warmup 4
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one micro-step of BASELINE.json config 2 per GPU: 64 synthetic triplets (query 64
+tokens, positive and negative document 256 tokens each, full length), i.e. three encoder
+forward passes + SPLADELossV33 + backward, and on every `--accum`-th step the gradient
+all-reduce (N>1), clip, AdamW and LR-schedule update -- the work of
+ref:src/train/cli/train_v33_ddp.py:316-374.  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line (rank 0): metric triplets/s (whole job), roofline and cpu_baseline objects.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "opensearch-neural-pre-train_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_triplet(Sq: int, Sd: int, k: int, window: int = 64):
+    """Algorithmic FLOPs: forward per token 22*(Wqkv+Wo+Wi+Wo_mlp) + head + decoder,
+    attention 4*768*(#unmasked pairs); step = 3 x forward (backward = 2 x forward convention)."""
+    per_tok = 22 * (2 * 768 * 2304 + 2 * 768 * 768 + 2 * 768 * 2304 + 2 * 1152 * 768) + 2 * 768 * 768 + 2 * 768 * 50000
+
+    def attn(S):
+        band = sum(min(S - 1, i + window) - max(0, i - window) + 1 for i in range(S))
+        return 4 * 768 * (8 * S * S + 14 * band)
+    tokens = Sq + (1 + k) * Sd
+    fwd = per_tok * tokens + attn(Sq) + (1 + k) * attn(Sd)
+    dec_bwd_dense = 2 * (2 * 768 * 50000) * tokens          # dense dX + dW of the decoder
+    dec_bwd_sparse = 2 * 2 * 768 * 50000 * (2 + k)          # routed: one row per (sequence, vocab) entry
+    return {"fwd": fwd, "step": 3 * fwd, "step_executed": 3 * fwd - dec_bwd_dense + dec_bwd_sparse}
+
+
+def synth_ids(B, S, vocab, pad, gen, dev):
+    ids = torch.randint(6, pad, (B, S), generator=gen)
+    ids[:, 0] = 0
+    ids[:, -1] = 1
+    return ids.to(dev), torch.ones(B, S, dtype=torch.int64, device=dev)
+
+
+def make_batches(n, B, Sq, Sd, k, vocab, pad, seed, dev):
+    gen = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        q, qm = synth_ids(B, Sq, vocab, pad, gen, dev)
+        p, pm = synth_ids(B, Sd, vocab, pad, gen, dev)
+        n_, nm = synth_ids(B * k, Sd, vocab, pad, gen, dev)
+        out.append({"query_input_ids": q, "query_attention_mask": qm, "positive_input_ids": p,
+                    "positive_attention_mask": pm, "negative_input_ids": n_, "negative_attention_mask": nm,
+                    "num_negatives": k})
+    return out
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """The oracle (CPU restatement of the reference step, fp32, torch CPU threads = host cores given
+    to this process) on a bounded sample: B=4 triplets per micro-step, q64/d256 full length."""
+    from oracle import splade_oracle as O
+    cores = torch.get_num_threads()
+    cfg = O.EncoderConfig()
+    params = O.init_params(cfg, seed=42)
+    st = O.TrainState(params)
+    lc = O.LossConfig()
+    gen = torch.Generator().manual_seed(42)
+    times = []
+    t_start = time.time()
+    n = 0
+    while True:
+        b = O.synth_batch(4, 64, 256, cfg, gen, k=1, ragged=False)
+        t0 = time.time()
+        O.train_micro_steps(cfg, lc, st, [b], grad_accum=1, base_lr=5e-5, wd=0.01, clip=1.0, warmup=10,
+                            total_steps=1000, global_step=n)
+        times.append(time.time() - t0)
+        n += 1
+        if n >= 2 and (time.time() - t_start > seconds_budget or n >= 6):
+            break
+    timed = times[1:] if len(times) > 1 else times
+    return {"value": 4.0 * len(timed) / sum(timed), "unit": "triplets/s", "cores": cores, "kind": "port",
+            "sample": f"{len(timed)} timed micro-steps (after 1 warm-up) of 4 triplets q64/d256, oracle fp32 incl. "
+                      "clip+AdamW every step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--q-len", type=int, default=64)
+    ap.add_argument("--d-len", type=int, default=256)
+    ap.add_argument("--negatives", type=int, default=1)
+    ap.add_argument("--accum", type=int, default=4)
+    ap.add_argument("--cross-gpu-negatives", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from snx._lib import fn
+    from src.model.losses import SPLADELossV33
+    from src.model.splade_modern import SPLADEModernBERT
+    from src.train.config.v33 import V33Config
+    from src.train.core import ddp_trainer as T
+
+    torch.manual_seed(42)                       # same init on every rank (DDP would broadcast rank 0)
+    import logging
+    logging.getLogger("src.model.splade_modern").setLevel(logging.ERROR)
+    model = SPLADEModernBERT().to(dev)
+    config = V33Config()
+    config.training.gradient_accumulation_steps = args.accum
+    wrapped = T.NativeDataParallel(model)
+    loss_fn = SPLADELossV33(lambda_q=config.loss.lambda_q, lambda_d=config.loss.lambda_d,
+                            temperature=config.loss.temperature, flops_warmup_steps=config.loss.flops_warmup_steps,
+                            lambda_initial_ratio=config.loss.lambda_initial_ratio).to(dev)
+    optimizer = T.build_optimizer(wrapped, config)
+    scheduler = T.build_scheduler(optimizer, 100, 10000)
+    B, Sq, Sd, k = args.batch, args.q_len, args.d_len, args.negatives
+    n_batches = min(args.steps + args.warmup, 8)
+    batches = make_batches(n_batches, B, Sq, Sd, k, model.vocab_size, model.config.pad_token_id, 42 + rank, dev)
+    xneg = args.cross_gpu_negatives
+    state = {"i": 0, "gs": 0}
+
+    def one_step():
+        b = batches[state["i"] % n_batches]
+        loss, _ = T.micro_step(wrapped, loss_fn, b, state["gs"], dev, args.accum, xneg)
+        state["i"] += 1
+        if state["i"] % args.accum == 0:
+            T.optimizer_step(wrapped, optimizer, scheduler, config)
+            state["gs"] += 1
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    wrapped.zero_grad()
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = float(loss)
+
+    fl = flops_per_triplet(Sq, Sd, k)
+    triplets_per_s = args.steps * B * world / dt
+    result = {
+        "metric": "triplets/sec (q64/d256, bs=64/GPU)", "value": triplets_per_s, "unit": "triplets/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SPLADEModernBERT 149M (A.X-Encoder-base geometry, random init) DDP step: "
+                               f"bs={B}/GPU, q{Sq}/d{Sd}, {k} neg, InfoNCE+FLOPS, grad-accum {args.accum}, "
+                               f"AdamW+clip every {args.accum} micro-steps"
+                               + (", cross-GPU in-batch negatives" if xneg else ""),
+                   "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": final_loss},
+        "mfma_roofline_frac_step": triplets_per_s * fl["step"] / (world * PEAK_BF16_TFLOPS * 1e12),
+        "mfma_roofline_frac_executed": triplets_per_s * fl["step_executed"] / (world * PEAK_BF16_TFLOPS * 1e12),
+        "gflop_per_triplet": {"algorithmic_3x_fwd": fl["step"] / 1e9, "executed_sparse_decoder_bwd": fl["step_executed"] / 1e9},
+    }
+
+    # ---- per-kernel-class attribution (HIP events on the launch stream, a few extra steps) ----
+    if rank == 0 and not args.no_profile:
+        ncls = fn("snx_prof_num_classes")()
+        names = [fn("snx_prof_class_name")(i).decode() for i in range(ncls)]
+        fn("snx_prof_enable")(1)
+        psteps = args.accum
+        for _ in range(psteps):
+            one_step()
+        torch.cuda.synchronize()
+        ms = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)(); work = (C.c_double * ncls)()
+        fn("snx_prof_read")(ms, cnt, work)
+        fn("snx_prof_enable")(0)
+        classes = {}
+        for i, nme in enumerate(names):
+            if cnt[i]:
+                classes[nme] = {"ms_per_step": ms[i] / psteps, "launches_per_step": cnt[i] / psteps,
+                                "avg_us": 1000.0 * ms[i] / cnt[i], "work_per_s": work[i] / (ms[i] * 1e-3)}
+        mfma = {"gemm_nt_bf16", "gemm_nt_resid", "gemm_tn_accum", "decoder_splade_fwd", "attn_fwd", "attn_bwd"}
+        dom = max((c for c in classes if c in mfma), key=lambda c: classes[c]["ms_per_step"])
+        ach = classes[dom]["work_per_s"] / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+                              "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                              "avg_launch_us": classes[dom]["avg_us"],
+                              "note": "algorithmic FLOPs of every launch of this kernel class in a step / summed "
+                                      "HIP-event durations of those launches (rank 0, profiled extra steps)"}
+        result["kernel_classes"] = classes
+    elif world > 1 and not args.no_profile:
+        for _ in range(args.accum):     # keep collectives matched with rank 0's profiled steps
+            one_step()
+        torch.cuda.synchronize()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

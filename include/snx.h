@@ -161,6 +161,15 @@ int snx_splade_bwd(const float* g, const uint32_t* keys, const void* Hd, const v
                    void* dHd, float* gradE, float* gradb, void* reserved, int32_t T, int32_t nseq,
                    int32_t max_seqlen, int32_t V, int32_t H, hipStream_t stream);
 
+/* ---- optional per-kernel-class timing inside the model entry points (HIP events recorded on
+ * the launch stream around every kernel class; off by default).  snx_prof_read synchronises on
+ * the recorded events and returns, per class, elapsed ms, launch count and algorithmic work
+ * (FLOPs for MFMA-bound classes, bytes for HBM-bound ones). */
+int snx_prof_enable(int32_t on);
+int32_t snx_prof_num_classes(void);
+const char* snx_prof_class_name(int32_t i);
+int snx_prof_read(double* ms /*[host]*/, int64_t* launches /*[host]*/, double* work /*[host]*/);
+
 #ifdef __cplusplus
 }
 #endif

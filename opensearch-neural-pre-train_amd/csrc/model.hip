@@ -3,6 +3,7 @@
 // One call = one `SPLADEModernBERT.forward` (ref:src/model/splade_modern.py:50-88 ->
 // transformers modeling_modernbert.py:434-478,522-550) or its complete backward.
 // No allocation, no host sync, caller-owned buffers, stream-ordered, graph-capturable.
+#include <vector>
 #include "common.h"
 #include "snx.h"
 
@@ -140,6 +141,35 @@ __global__ void add_bf16_into_f32_kernel(float* __restrict__ dst, const bf16_t* 
   *(f32x4*)(dst + i * 4) = a;
 }
 
+
+// ---- optional per-kernel-class timing (HIP events on the launch stream) -------------------
+// Disabled by default (zero overhead: one predictable branch).  bench.py enables it for a few
+// extra steps to attribute time and algorithmic FLOPs/bytes to kernel classes.
+enum ProfClass { PC_GEMM_NT = 0, PC_GEMM_NT_RESID, PC_GEMM_TN, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD,
+                 PC_ROPE, PC_GEGLU, PC_DECODER_SPLADE, PC_SPLADE_BWD, PC_EMBED, PC_CAST, PC_COUNT };
+const char* const kProfNames[PC_COUNT] = {"gemm_nt_bf16", "gemm_nt_resid", "gemm_tn_accum", "attn_fwd", "attn_bwd",
+                                          "ln_fwd", "ln_bwd", "rope", "geglu", "decoder_splade_fwd", "splade_bwd",
+                                          "embed_ln", "cast"};
+struct ProfRec { int cls; double work; hipEvent_t a, b; };
+struct Prof {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+  }
+} g_prof;
+
+struct ProfScope {
+  bool live; hipStream_t st; ProfRec r;
+  ProfScope(int cls, double work, hipStream_t s) : live(g_prof.on), st(s) {
+    if (live) { r.cls = cls; r.work = work; r.a = g_prof.get(); r.b = g_prof.get(); hipEventRecord(r.a, st); }
+  }
+  ~ProfScope() { if (live) { hipEventRecord(r.b, st); g_prof.recs.push_back(r); } }
+};
+#define PROF(cls, work) ProfScope prof_scope__(cls, (double)(work), st)
+
 #define RC(call)            \
   do {                      \
     int rc__ = (call);      \
@@ -220,25 +250,28 @@ extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* par
   auto F = [&](int idx) { return (const float*)params[idx]; };
   auto hbuf = [&](int i) { return (float*)(sv + s.h[i]); };
 
-  RC(snx_embed_ln_fwd(ids, F(p.tok_emb()), F(p.emb_norm()), hbuf(0), sv + s.x_attn[0], T, H, d->ln_eps, st));
+  const double TH = (double)T * H;
+  { PROF(PC_EMBED, TH * 10); RC(snx_embed_ln_fwd(ids, F(p.tok_emb()), F(p.emb_norm()), hbuf(0), sv + s.x_attn[0], T, H, d->ln_eps, st)); }
   for (int l = 0; l < L; ++l) {
     const bool global = (l % d->global_every) == 0;
-    if (l > 0) RC(snx_ln_fwd(hbuf(2 * l), F(p.attn_norm(l)), sv + s.x_attn[l], T, H, d->ln_eps, st));
-    RC(snx_gemm_nt_bf16(sv + s.x_attn[l], wc + c.wqkv[l], sv + s.qkv[l], T, 3 * H, H, st));
-    RC(snx_rope_inplace(sv + s.qkv[l], global ? rope_global : rope_local, pos, T, d->heads, 0, st));
-    RC(snx_attn_fwd(sv + s.qkv[l], cu_seqlens, mask, sv + s.attn[l], (float*)(sv + s.lse[l]), T, nseq, max_seqlen,
-                    d->heads, d->head_dim, global ? -1 : d->window, st));
-    RC(snx_gemm_nt_resid(sv + s.attn[l], wc + c.wo[l], hbuf(2 * l), hbuf(2 * l + 1), T, H, H, st));
-    RC(snx_ln_fwd(hbuf(2 * l + 1), F(p.mlp_norm(l)), sv + s.x_mlp[l], T, H, d->ln_eps, st));
-    RC(snx_gemm_nt_bf16(sv + s.x_mlp[l], wc + c.wi[l], sv + s.u[l], T, 2 * I, H, st));
-    RC(snx_geglu_fwd(sv + s.u[l], sv + s.y[l], T, I, st));
-    RC(snx_gemm_nt_resid(sv + s.y[l], wc + c.wom[l], hbuf(2 * l + 1), hbuf(2 * l + 2), T, H, I, st));
+    if (l > 0) { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l), F(p.attn_norm(l)), sv + s.x_attn[l], T, H, d->ln_eps, st)); }
+    { PROF(PC_GEMM_NT, 2.0 * T * 3 * H * H); RC(snx_gemm_nt_bf16(sv + s.x_attn[l], wc + c.wqkv[l], sv + s.qkv[l], T, 3 * H, H, st)); }
+    { PROF(PC_ROPE, TH * 8); RC(snx_rope_inplace(sv + s.qkv[l], global ? rope_global : rope_local, pos, T, d->heads, 0, st)); }
+    { PROF(PC_ATTN_FWD, 4.0 * TH * (global ? max_seqlen : (2 * d->window + 1 < max_seqlen ? 2 * d->window + 1 : max_seqlen)));
+      RC(snx_attn_fwd(sv + s.qkv[l], cu_seqlens, mask, sv + s.attn[l], (float*)(sv + s.lse[l]), T, nseq, max_seqlen,
+                      d->heads, d->head_dim, global ? -1 : d->window, st)); }
+    { PROF(PC_GEMM_NT_RESID, 2.0 * TH * H); RC(snx_gemm_nt_resid(sv + s.attn[l], wc + c.wo[l], hbuf(2 * l), hbuf(2 * l + 1), T, H, H, st)); }
+    { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l + 1), F(p.mlp_norm(l)), sv + s.x_mlp[l], T, H, d->ln_eps, st)); }
+    { PROF(PC_GEMM_NT, 2.0 * T * 2 * I * H); RC(snx_gemm_nt_bf16(sv + s.x_mlp[l], wc + c.wi[l], sv + s.u[l], T, 2 * I, H, st)); }
+    { PROF(PC_GEGLU, (double)T * I * 6); RC(snx_geglu_fwd(sv + s.u[l], sv + s.y[l], T, I, st)); }
+    { PROF(PC_GEMM_NT_RESID, 2.0 * TH * I); RC(snx_gemm_nt_resid(sv + s.y[l], wc + c.wom[l], hbuf(2 * l + 1), hbuf(2 * l + 2), T, H, I, st)); }
   }
-  RC(snx_ln_fwd(hbuf(2 * L), F(p.final_norm()), sv + s.xf, T, H, d->ln_eps, st));
-  RC(snx_gemm_nt_bf16(sv + s.xf, wc + c.dense, sv + s.dd, T, H, H, st));
-  RC(snx_gelu_ln_fwd(sv + s.dd, F(p.head_norm()), sv + s.hd, T, H, d->ln_eps, st));
-  RC(snx_decoder_splade_fwd(sv + s.hd, wc + c.emb, F(p.dec_bias()), cu_seqlens, mask, sparse,
-                            (uint32_t*)(sv + s.keys), token_weights, sv + s.rowpart, T, nseq, max_seqlen, V, H, st));
+  { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * L), F(p.final_norm()), sv + s.xf, T, H, d->ln_eps, st)); }
+  { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(sv + s.xf, wc + c.dense, sv + s.dd, T, H, H, st)); }
+  { PROF(PC_LN_FWD, TH * 4); RC(snx_gelu_ln_fwd(sv + s.dd, F(p.head_norm()), sv + s.hd, T, H, d->ln_eps, st)); }
+  { PROF(PC_DECODER_SPLADE, 2.0 * TH * V);
+    RC(snx_decoder_splade_fwd(sv + s.hd, wc + c.emb, F(p.dec_bias()), cu_seqlens, mask, sparse,
+                              (uint32_t*)(sv + s.keys), token_weights, sv + s.rowpart, T, nseq, max_seqlen, V, H, st)); }
   return SNX_OK;
 }
 
@@ -268,42 +301,74 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
   char *A = sc + b.a, *Bb = sc + b.b, *Cc = sc + b.c, *Wd = sc + b.w;
   const long n4 = (long)T * H / 4;
 
+  const double TH = (double)T * H;
   // SPLADE tail + decoder (sparse routed), head
-  RC(snx_splade_bwd(g_sparse, (const uint32_t*)(sv + s.keys), sv + s.hd, wc + c.emb, cu_seqlens, A, G(p.tok_emb()),
-                    G(p.dec_bias()), nullptr, T, nseq, max_seqlen, V, H, st));
-  RC(snx_gelu_ln_bwd(A, sv + s.dd, F(p.head_norm()), Bb, G(p.head_norm()), T, H, d->ln_eps, st));
-  RC(snx_gemm_tn_accum(Bb, sv + s.xf, G(p.head_dense()), T, H, H, st));
-  RC(snx_gemm_nt_bf16(Bb, wc + c.dense_t, A, T, H, H, st));
-  RC(snx_ln_bwd(A, hbuf(2 * L), F(p.final_norm()), dh, G(p.final_norm()), T, H, d->ln_eps, 1, st));
+  { PROF(PC_SPLADE_BWD, 2.0 * 2.0 * nseq * V * H);
+    RC(snx_splade_bwd(g_sparse, (const uint32_t*)(sv + s.keys), sv + s.hd, wc + c.emb, cu_seqlens, A, G(p.tok_emb()),
+                      G(p.dec_bias()), nullptr, T, nseq, max_seqlen, V, H, st)); }
+  { PROF(PC_LN_BWD, TH * 6); RC(snx_gelu_ln_bwd(A, sv + s.dd, F(p.head_norm()), Bb, G(p.head_norm()), T, H, d->ln_eps, st)); }
+  { PROF(PC_GEMM_TN, 2.0 * TH * H); RC(snx_gemm_tn_accum(Bb, sv + s.xf, G(p.head_dense()), T, H, H, st)); }
+  { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(Bb, wc + c.dense_t, A, T, H, H, st)); }
+  { PROF(PC_LN_BWD, TH * 10); RC(snx_ln_bwd(A, hbuf(2 * L), F(p.final_norm()), dh, G(p.final_norm()), T, H, d->ln_eps, 1, st)); }
 
   for (int l = L - 1; l >= 0; --l) {
     const bool global = (l % d->global_every) == 0;
+    const double attn_keys = global ? max_seqlen : (2 * d->window + 1 < max_seqlen ? 2 * d->window + 1 : max_seqlen);
     // ---- MLP:  h[2l+2] = h[2l+1] + Wo( gelu(a) * g ),  [a|g] = Wi( LN(h[2l+1]) )
-    RC(snx_cast_bf16(dh, A, (int64_t)T * H, st));                                  // grad of the bf16 branch output
-    RC(snx_gemm_tn_accum(A, sv + s.y[l], G(p.wo_mlp(l)), T, H, I, st));
-    RC(snx_gemm_nt_bf16(A, wc + c.wom_t[l], Cc, T, I, H, st));                     // dy [T,I]
-    RC(snx_geglu_bwd(sv + s.u[l], Cc, Wd, T, I, st));                              // du [T,2I]
-    RC(snx_gemm_tn_accum(Wd, sv + s.x_mlp[l], G(p.wi(l)), T, 2 * I, H, st));
-    RC(snx_gemm_nt_bf16(Wd, wc + c.wi_t[l], A, T, H, 2 * I, st));                  // dx [T,H]
-    RC(snx_ln_bwd(A, hbuf(2 * l + 1), F(p.mlp_norm(l)), dh, G(p.mlp_norm(l)), T, H, d->ln_eps, 0, st));
+    { PROF(PC_CAST, TH * 6); RC(snx_cast_bf16(dh, A, (int64_t)T * H, st)); }          // grad of the bf16 branch output
+    { PROF(PC_GEMM_TN, 2.0 * TH * I); RC(snx_gemm_tn_accum(A, sv + s.y[l], G(p.wo_mlp(l)), T, H, I, st)); }
+    { PROF(PC_GEMM_NT, 2.0 * TH * I); RC(snx_gemm_nt_bf16(A, wc + c.wom_t[l], Cc, T, I, H, st)); }   // dy [T,I]
+    { PROF(PC_GEGLU, (double)T * I * 10); RC(snx_geglu_bwd(sv + s.u[l], Cc, Wd, T, I, st)); }        // du [T,2I]
+    { PROF(PC_GEMM_TN, 2.0 * TH * 2 * I); RC(snx_gemm_tn_accum(Wd, sv + s.x_mlp[l], G(p.wi(l)), T, 2 * I, H, st)); }
+    { PROF(PC_GEMM_NT, 2.0 * TH * 2 * I); RC(snx_gemm_nt_bf16(Wd, wc + c.wi_t[l], A, T, H, 2 * I, st)); }   // dx [T,H]
+    { PROF(PC_LN_BWD, TH * 14); RC(snx_ln_bwd(A, hbuf(2 * l + 1), F(p.mlp_norm(l)), dh, G(p.mlp_norm(l)), T, H, d->ln_eps, 0, st)); }
     // ---- attention:  h[2l+1] = h[2l] + Wo( attn( rope( Wqkv( LN(h[2l]) ) ) ) )
-    RC(snx_cast_bf16(dh, A, (int64_t)T * H, st));
-    RC(snx_gemm_tn_accum(A, sv + s.attn[l], G(p.wo(l)), T, H, H, st));
-    RC(snx_gemm_nt_bf16(A, wc + c.wo_t[l], Bb, T, H, H, st));                      // d(attn out)
-    RC(snx_attn_bwd(sv + s.qkv[l], sv + s.attn[l], Bb, (const float*)(sv + s.lse[l]), cu_seqlens, mask,
-                    (float*)(sc + b.delta), Wd, T, nseq, max_seqlen, d->heads, d->head_dim,
-                    global ? -1 : d->window, st));
-    RC(snx_rope_inplace(Wd, global ? rope_global : rope_local, pos, T, d->heads, 1, st));
-    RC(snx_gemm_tn_accum(Wd, sv + s.x_attn[l], G(p.wqkv(l)), T, 3 * H, H, st));
-    RC(snx_gemm_nt_bf16(Wd, wc + c.wqkv_t[l], A, T, H, 3 * H, st));                // dx [T,H]
+    { PROF(PC_CAST, TH * 6); RC(snx_cast_bf16(dh, A, (int64_t)T * H, st)); }
+    { PROF(PC_GEMM_TN, 2.0 * TH * H); RC(snx_gemm_tn_accum(A, sv + s.attn[l], G(p.wo(l)), T, H, H, st)); }
+    { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(A, wc + c.wo_t[l], Bb, T, H, H, st)); }    // d(attn out)
+    { PROF(PC_ATTN_BWD, 10.0 * TH * attn_keys);
+      RC(snx_attn_bwd(sv + s.qkv[l], sv + s.attn[l], Bb, (const float*)(sv + s.lse[l]), cu_seqlens, mask,
+                      (float*)(sc + b.delta), Wd, T, nseq, max_seqlen, d->heads, d->head_dim,
+                      global ? -1 : d->window, st)); }
+    { PROF(PC_ROPE, TH * 8); RC(snx_rope_inplace(Wd, global ? rope_global : rope_local, pos, T, d->heads, 1, st)); }
+    { PROF(PC_GEMM_TN, 2.0 * TH * 3 * H); RC(snx_gemm_tn_accum(Wd, sv + s.x_attn[l], G(p.wqkv(l)), T, 3 * H, H, st)); }
+    { PROF(PC_GEMM_NT, 2.0 * TH * 3 * H); RC(snx_gemm_nt_bf16(Wd, wc + c.wqkv_t[l], A, T, H, 3 * H, st)); }   // dx [T,H]
     if (l > 0) {
+      PROF(PC_LN_BWD, TH * 14);
       RC(snx_ln_bwd(A, hbuf(2 * l), F(p.attn_norm(l)), dh, G(p.attn_norm(l)), T, H, d->ln_eps, 0, st));
     } else {
+      PROF(PC_CAST, TH * 10);
       hipLaunchKernelGGL(add_bf16_into_f32_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dh, (const bf16_t*)A, n4);
       SNX_CHECK_LAUNCH();
     }
   }
-  RC(snx_embed_ln_bwd(dh, ids, F(p.tok_emb()), F(p.emb_norm()), G(p.tok_emb()), G(p.emb_norm()), T, H, d->ln_eps,
-                      d->pad_id, st));
+  { PROF(PC_EMBED, TH * 12);
+    RC(snx_embed_ln_bwd(dh, ids, F(p.tok_emb()), F(p.emb_norm()), G(p.tok_emb()), G(p.emb_norm()), T, H, d->ln_eps,
+                        d->pad_id, st)); }
+  return SNX_OK;
+}
+
+// ---- profiling API (see ProfScope above) ---------------------------------------------------
+extern "C" int snx_prof_enable(int32_t on) {
+  g_prof.on = on != 0;
+  return SNX_OK;
+}
+
+extern "C" int32_t snx_prof_num_classes(void) { return PC_COUNT; }
+extern "C" const char* snx_prof_class_name(int32_t i) { return (i >= 0 && i < PC_COUNT) ? kProfNames[i] : ""; }
+
+// Synchronises on the recorded events; fills ms[c], launches[c], work[c] (algorithmic FLOPs for
+// the MFMA classes, algorithmic bytes for the HBM-bound ones) per class and clears the records.
+extern "C" int snx_prof_read(double* ms, int64_t* launches, double* work) {
+  if (!ms || !launches || !work) return SNX_E_ARG;
+  for (int c = 0; c < PC_COUNT; ++c) { ms[c] = 0; launches[c] = 0; work[c] = 0; }
+  for (auto& r : g_prof.recs) {
+    hipEventSynchronize(r.b);
+    float t = 0.f;
+    hipEventElapsedTime(&t, r.a, r.b);
+    ms[r.cls] += t; launches[r.cls] += 1; work[r.cls] += r.work;
+    g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b);
+  }
+  g_prof.recs.clear();
   return SNX_OK;
 }

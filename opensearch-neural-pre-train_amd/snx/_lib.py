@@ -50,6 +50,10 @@ SIGNATURES = {
     "snx_model_backward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P]),
     "snx_param_count": (I32, [P]),
     "snx_version": (I32, []),
+    "snx_prof_enable": (I32, [I32]),
+    "snx_prof_num_classes": (I32, []),
+    "snx_prof_class_name": (C.c_char_p, [I32]),
+    "snx_prof_read": (I32, [P, P, P]),
 }
 
 _lib = None
