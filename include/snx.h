@@ -68,7 +68,10 @@ int snx_weight_cache_refresh(const snx_model_desc* d, const void* const* params 
 
 /* Activation arena size for one forward over T token rows (save_for_bwd=0: inference plan). */
 size_t snx_model_workspace_bytes(const snx_model_desc* d, int32_t T, int32_t nseq, int32_t save_for_bwd);
-size_t snx_model_bwd_workspace_bytes(const snx_model_desc* d, int32_t T, int32_t nseq);
+size_t snx_model_bwd_workspace_bytes(const snx_model_desc* d, int32_t T, int32_t nseq, int32_t max_seqlen);
+/* byte offset, inside a save_for_bwd arena, of the packed arg-max keys u32 [nseq, vocab]
+ * (bf16 bits of relu(logit) << 16 | 0xFFFF - row): lets a caller inspect the max-pool routing. */
+size_t snx_model_keys_offset(const snx_model_desc* d, int32_t T, int32_t nseq);
 
 /* SPLADEModernBERT.forward (ref:src/model/splade_modern.py:50-88):
  *   ids,mask [T] int64; pos [T] int32 (position of each row inside its sequence);
@@ -127,9 +130,10 @@ int snx_embed_ln_fwd(const int64_t* ids, const float* E, const float* w, float* 
                      int32_t H, float eps, hipStream_t stream);
 /* ModernBertPredictionHead tail (hf:489-490): LN(gelu(d)). */
 int snx_gelu_ln_fwd(const void* d, const float* w, void* x_out, int32_t T, int32_t H, float eps, hipStream_t stream);
-/* backward of the three above; dh (+)= dx, dw += ... (overwrite=1: dh = dx). */
-int snx_ln_bwd(const void* dy, const float* h, const float* w, float* dh, float* dw, int32_t T, int32_t H, float eps,
-               int32_t overwrite, hipStream_t stream);
+/* backward of the three above; dh (+)= dx, dw += ... (overwrite=1: dh = dx); dh_bf16 (nullable)
+ * also receives bf16(dh), the gradient of the next bf16 branch output (saves a cast pass). */
+int snx_ln_bwd(const void* dy, const float* h, const float* w, float* dh, void* dh_bf16, float* dw, int32_t T,
+               int32_t H, float eps, int32_t overwrite, hipStream_t stream);
 int snx_embed_ln_bwd(const float* dh, const int64_t* ids, const float* E, const float* w, float* gradE, float* dw,
                      int32_t T, int32_t H, float eps, int32_t pad_id, hipStream_t stream);
 int snx_gelu_ln_bwd(const void* dy, const void* d, const float* w, void* dd, float* dw, int32_t T, int32_t H,
@@ -156,9 +160,11 @@ size_t snx_splade_head_scratch_bytes(int32_t T, int32_t V);
 int snx_decoder_splade_fwd(const void* Hd, const void* W, const float* bias, const int32_t* cu_seqlens,
                            const int64_t* mask, float* sparse, uint32_t* keys, float* token_weights, void* scratch,
                            int32_t T, int32_t nseq, int32_t max_seqlen, int32_t V, int32_t K, hipStream_t stream);
-/* arg-max-routed backward: dHd [T,H] bf16 (overwritten), gradE [V,H] += , gradb [V] += . */
+/* arg-max-routed backward: dHd [T,H] bf16 (overwritten), gradE [V,H] += , gradb [V] += ;
+ * scratch: snx_splade_bwd_scratch_bytes() bytes (per-row bucket lists). */
+size_t snx_splade_bwd_scratch_bytes(int32_t nseq, int32_t max_seqlen, int32_t V);
 int snx_splade_bwd(const float* g, const uint32_t* keys, const void* Hd, const void* W, const int32_t* cu_seqlens,
-                   void* dHd, float* gradE, float* gradb, void* reserved, int32_t T, int32_t nseq,
+                   void* dHd, float* gradE, float* gradb, void* scratch, int32_t T, int32_t nseq,
                    int32_t max_seqlen, int32_t V, int32_t H, hipStream_t stream);
 
 /* ---- optional per-kernel-class timing inside the model entry points (HIP events recorded on

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ h, const int64_t* __restrict__ ids,
                                                      const float* __restrict__ E, const bf16_t* __restrict__ d,
                                                      const float* __restrict__ w, float* __restrict__ dh,
+                                                     bf16_t* __restrict__ dh_bf16,
                                                      float* __restrict__ gradE, bf16_t* __restrict__ dd,
                                                      float* __restrict__ dw, int T, int H, float eps,
                                                      int rows_per_block, int pad_id) {
@@ -255,8 +256,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
       for (int i = 0; i < NV; ++i) cur.v[i] += g.v[i];
       cur.store_f32(dh + (long)t * H, lane);
+      if (dh_bf16) cur.store_bf16(dh_bf16 + (long)t * H, lane);   // grad of the next bf16 branch output
     } else if (MODE == 3) {
       g.store_f32(dh + (long)t * H, lane);
+      if (dh_bf16) g.store_bf16(dh_bf16 + (long)t * H, lane);
     } else if (MODE == 1) {
       if (id != pad_id) {                                  // nn.Embedding(padding_idx): no grad to the pad row
         float* dst = gradE + id * (long)H;
@@ -291,19 +294,19 @@ static inline int ln_bwd_rows_per_block(int T) {
   return rpb < ROWS_PER_BLOCK ? ROWS_PER_BLOCK : rpb;
 }
 
-extern "C" int snx_ln_bwd(const void* dy, const float* h, const float* w, float* dh, float* dw, int32_t T,
-                          int32_t H, float eps, int32_t overwrite, hipStream_t st) {
+extern "C" int snx_ln_bwd(const void* dy, const float* h, const float* w, float* dh, void* dh_bf16, float* dw,
+                          int32_t T, int32_t H, float eps, int32_t overwrite, hipStream_t st) {
   if (!dy || !h || !w || !dh || !dw || T <= 0) return SNX_E_ARG;
   if (bad_h(H)) return SNX_E_SHAPE;
   const int rpb = ln_bwd_rows_per_block(T);
   if (overwrite) {
     DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 3>), dim3(cdiv(T, rpb)), dim3(256), 0, st,
-                                      (const bf16_t*)dy, nullptr, h, nullptr, nullptr, nullptr, w, dh, nullptr,
-                                      nullptr, dw, T, H, eps, rpb, -1));
+                                      (const bf16_t*)dy, nullptr, h, nullptr, nullptr, nullptr, w, dh,
+                                      (bf16_t*)dh_bf16, nullptr, nullptr, dw, T, H, eps, rpb, -1));
   } else {
     DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 0>), dim3(cdiv(T, rpb)), dim3(256), 0, st,
-                                      (const bf16_t*)dy, nullptr, h, nullptr, nullptr, nullptr, w, dh, nullptr,
-                                      nullptr, dw, T, H, eps, rpb, -1));
+                                      (const bf16_t*)dy, nullptr, h, nullptr, nullptr, nullptr, w, dh,
+                                      (bf16_t*)dh_bf16, nullptr, nullptr, dw, T, H, eps, rpb, -1));
   }
   SNX_CHECK_LAUNCH();
   return SNX_OK;
@@ -315,8 +318,8 @@ extern "C" int snx_embed_ln_bwd(const float* dh, const int64_t* ids, const float
   if (bad_h(H)) return SNX_E_SHAPE;
   const int rpb = ln_bwd_rows_per_block(T);
   DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 1>), dim3(cdiv(T, rpb)), dim3(256), 0, st, nullptr, dh,
-                                    nullptr, ids, E, nullptr, w, nullptr, gradE, nullptr, dw, T, H, eps, rpb,
-                                    pad_id));
+                                    nullptr, ids, E, nullptr, w, nullptr, nullptr, gradE, nullptr, dw, T, H, eps,
+                                    rpb, pad_id));
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }
@@ -328,7 +331,7 @@ extern "C" int snx_gelu_ln_bwd(const void* dy, const void* d, const float* w, vo
   const int rpb = ln_bwd_rows_per_block(T);
   DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 2>), dim3(cdiv(T, rpb)), dim3(256), 0, st,
                                     (const bf16_t*)dy, nullptr, nullptr, nullptr, nullptr, (const bf16_t*)d, w,
-                                    nullptr, nullptr, (bf16_t*)dd, dw, T, H, eps, rpb, -1));
+                                    nullptr, nullptr, nullptr, (bf16_t*)dd, dw, T, H, eps, rpb, -1));
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }

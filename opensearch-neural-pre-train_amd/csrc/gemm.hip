@@ -20,23 +20,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
   for (int i = 0; i < Core::MI; ++i)
 #pragma unroll
     for (int j = 0; j < Core::NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  Core::mainloop(A, K, m0, M, B, K, n0, N, K, smem, acc);
+  Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
+  // transposed accumulators: this lane owns columns col..col+3 of row `row`
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 #pragma unroll
   for (int i = 0; i < Core::MI; ++i) {
+    const int row = m0 + wm * Core::WTM + i * 16 + (lane & 15);
+    if (row >= M) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + Core::acc_row(i, r);
-      if (row >= M) continue;
-#pragma unroll
-      for (int j = 0; j < Core::NI; ++j) {
-        const int col = n0 + Core::acc_col(j);
-        if (col >= N) continue;
-        const long o = (long)row * N + col;
-        if (EPI == EPI_STORE_BF16) {
-          Cb[o] = f2bf(acc[i][j][r]);
-        } else {
-          Hout[o] = Hin[o] + rbf(acc[i][j][r]);     // Linear output is bf16, residual stream fp32
-        }
+    for (int j = 0; j < Core::NI; ++j) {
+      const int col = n0 + wn * Core::WTN + j * 16 + (lane >> 4) * 4;
+      if (col >= N) continue;                       // N % 4 == 0: the 4 columns are in or out together
+      const long o = (long)row * N + col;
+      const f32x4 v = acc[i][j];
+      if (EPI == EPI_STORE_BF16) {
+        *(bf16x4*)(Cb + o) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      } else {                                      // Linear output is bf16, residual stream fp32
+        const f32x4 h = *(const f32x4*)(Hin + o);
+        *(f32x4*)(Hout + o) = (f32x4){h[0] + rbf(v[0]), h[1] + rbf(v[1]), h[2] + rbf(v[2]), h[3] + rbf(v[3])};
       }
     }
   }
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
 template <int EPI>
 static int launch_nt(const void* A, const void* B, int M, int N, int K, void* Cb, const float* Hin, float* Hout,
                      hipStream_t st) {
-  if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0) return SNX_E_SHAPE;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0) return SNX_E_SHAPE;
   if (!A || !B) return SNX_E_ARG;
   constexpr int BM = 128, BN = 128;
   using Core = GemmCore<BM, BN, 2, 2>;
@@ -171,7 +173,7 @@ extern "C" int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32
   if (!dY || !X || !dW) return SNX_E_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128)) return SNX_E_SHAPE;
   const int tiles = (N / 128) * (K / 128);
-  int splits = cdiv(512, tiles);
+  int splits = cdiv(304, tiles);            // ~1.2 blocks per CU: fewer partial tiles -> fewer float atomics
   const int max_splits = cdiv(M, 256);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

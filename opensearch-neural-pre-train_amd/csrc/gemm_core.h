@@ -48,6 +48,10 @@ struct GemmCore {
   }
 
   // acc must be zero-initialised (or hold the running sum) by the caller.
+  // TRANSPOSED=false: acc[i][j][r] = C[wm*WTM + i*16 + 4g + r][wn*WTN + j*16 + li]   (g = lane>>4, li = lane&15)
+  // TRANSPOSED=true : acc[i][j][r] = C[wm*WTM + i*16 + li][wn*WTN + j*16 + 4g + r]   -- each lane owns 4
+  //                   CONSECUTIVE columns of one row: 8-byte bf16 / 16-byte fp32 epilogue accesses.
+  template <bool TRANSPOSED = false>
   static __device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, long lda, int m0, int M,
                                                   const bf16_t* __restrict__ B, long ldb, int n0, int N,
                                                   int K, char* smem, f32x4 (&acc)[MI][NI]) {
@@ -80,7 +84,8 @@ struct GemmCore {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = TRANSPOSED ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
   }

@@ -19,10 +19,11 @@ struct LossWs {
   float *part_inb, *part_hard, *part_pos, *part_sc;   // [nchunk][B*Bp], [nchunk][B*k], [nchunk][B], [nchunk][8]
   float *mean_q, *mean_p, *mean_n;                     // [V] each
   float *G, *Gh, *dpos;                                // [B*Bp], [B*k], [B]
+  float *red;                                          // [B*Bp + B*k + B] partials summed over chunks
 };
 
 static inline size_t ws_floats(int B, int Bp, int k, int V, int nchunk) {
-  return (size_t)nchunk * ((size_t)B * Bp + (size_t)B * k + B + 8) + 3 * (size_t)V + (size_t)B * Bp + (size_t)B * k + B;
+  return (size_t)nchunk * ((size_t)B * Bp + (size_t)B * k + B + 8) + 3 * (size_t)V + 2 * ((size_t)B * Bp + (size_t)B * k + B);
 }
 static inline LossWs carve(float* w, int B, int Bp, int k, int V, int nchunk) {
   LossWs s;
@@ -35,7 +36,8 @@ static inline LossWs carve(float* w, int B, int Bp, int k, int V, int nchunk) {
   s.mean_n = w; w += V;
   s.G = w; w += (size_t)B * Bp;
   s.Gh = w; w += (size_t)B * k;
-  s.dpos = w;
+  s.dpos = w; w += B;
+  s.red = w;
   return s;
 }
 static inline int pick_ch(int B, int Bp) {
@@ -126,6 +128,29 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restri
   }
 }
 
+// sum the per-chunk partial dot products: one thread per output, coalesced across threads
+__global__ void loss_sum_partials_kernel(LossDims d, LossWs w) {
+  const int n1 = d.B * d.Bp, n2 = d.B * d.k, n3 = d.B;
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n1 + n2 + n3) return;
+  const float* src;
+  long stride;
+  int idx;
+  if (o < n1) { src = w.part_inb; stride = n1; idx = o; }
+  else if (o < n1 + n2) { src = w.part_hard; stride = n2; idx = o - n1; }
+  else { src = w.part_pos; stride = n3; idx = o - n1 - n2; }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 3 < d.nchunk; c += 4) {
+    s0 += src[(long)c * stride + idx];
+    s1 += src[(long)(c + 1) * stride + idx];
+    s2 += src[(long)(c + 2) * stride + idx];
+    s3 += src[(long)(c + 3) * stride + idx];
+  }
+  for (; c < d.nchunk; ++c) s0 += src[(long)c * stride + idx];
+  w.red[o] = (s0 + s1) + (s2 + s3);
+}
+
 // out[0]=loss [1]=infonce [2]=flops_q [3]=flops_d [4]=flops_neg [5]=margin_mse [6]=nonzero_q [7]=nonzero_d
 __global__ __launch_bounds__(256) void loss_reduce_kernel(LossDims d, LossWs w, const float* __restrict__ tpos,
                                                           const float* __restrict__ tneg, float* __restrict__ out) {
@@ -137,22 +162,16 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossDims d, LossWs w, 
   float* hard_raw = sm + d.B * NS;          // [B][k]  (un-tempered q.n)
   float* posd = hard_raw + d.B * d.k;       // [B]
   for (int pr = tid; pr < d.B * d.Bp; pr += 256) {
-    float s = 0.f;
-    for (int c = 0; c < d.nchunk; ++c) s += w.part_inb[(long)c * d.B * d.Bp + pr];
+    float s = w.red[pr];
     if (d.bf16_mm) s = rbf(s);
     sc[(pr / d.Bp) * NS + (pr % d.Bp)] = s * d.inv_tau;
   }
   for (int pr = tid; pr < d.B * d.k; pr += 256) {
-    float s = 0.f;
-    for (int c = 0; c < d.nchunk; ++c) s += w.part_hard[(long)c * d.B * d.k + pr];
+    const float s = w.red[d.B * d.Bp + pr];
     hard_raw[pr] = s;
     sc[(pr / d.k) * NS + d.Bp + (pr % d.k)] = s * d.inv_tau;
   }
-  for (int i = tid; i < d.B; i += 256) {
-    float s = 0.f;
-    for (int c = 0; c < d.nchunk; ++c) s += w.part_pos[(long)c * d.B + i];
-    posd[i] = s;
-  }
+  for (int i = tid; i < d.B; i += 256) posd[i] = w.red[d.B * d.Bp + d.B * d.k + i];
   float sca[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int c = tid; c < d.nchunk; c += 256)
     for (int e = 0; e < 5; ++e) sca[e] += w.part_sc[(long)c * 8 + e];
@@ -288,6 +307,8 @@ extern "C" int snx_loss_fwd(const float* q, const float* p, const float* n, cons
   LossWs w = carve((float*)workspace, d.B, d.Bp, d.k, d.V, d.nchunk);
   const size_t lds1 = (size_t)(d.B + d.Bp) * (d.CH + 1) * 4;
   hipLaunchKernelGGL(loss_partial_kernel, dim3(d.nchunk), dim3(256), lds1, st, q, p, n, d, w);
+  SNX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_sum_partials_kernel, dim3(cdiv(d.B * d.Bp + d.B * d.k + d.B, 256)), dim3(256), 0, st, d, w);
   SNX_CHECK_LAUNCH();
   const size_t lds2 = (size_t)(d.B * (d.Bp + d.k) + d.B * d.k + d.B) * 4;
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), lds2, st, d, w, tpos, tneg, out8);

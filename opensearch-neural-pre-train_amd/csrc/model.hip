@@ -111,10 +111,11 @@ struct BwdPlan {
   size_t c;         // bf16 [T,I]
   size_t w;         // bf16 [T,max(3H,2I)]
   size_t delta;     // fp32 [heads,T]
+  size_t splade;    // bucket lists of the routed SPLADE backward
   size_t total;
 };
 
-void plan_bwd(const snx_model_desc* d, long T, BwdPlan& p) {
+void plan_bwd(const snx_model_desc* d, long T, long nseq, long max_seqlen, BwdPlan& p) {
   const size_t H = d->hidden, I = d->inter;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
@@ -123,6 +124,7 @@ void plan_bwd(const snx_model_desc* d, long T, BwdPlan& p) {
   p.c = take(T * I * 2);
   p.w = take(T * (3 * H > 2 * I ? 3 * H : 2 * I) * 2);
   p.delta = take((size_t)d->heads * T * 4);
+  p.splade = take(snx_splade_bwd_scratch_bytes((int)nseq, (int)max_seqlen, d->vocab));
   p.total = off;
 }
 
@@ -221,11 +223,16 @@ extern "C" size_t snx_model_workspace_bytes(const snx_model_desc* d, int32_t T, 
   return s.total;
 }
 
-extern "C" size_t snx_model_bwd_workspace_bytes(const snx_model_desc* d, int32_t T, int32_t nseq) {
-  (void)nseq;
-  if (!desc_ok(d) || T <= 0) return 0;
+extern "C" size_t snx_model_keys_offset(const snx_model_desc* d, int32_t T, int32_t nseq) {
+  SavedPlan s;
+  if (!desc_ok(d) || T <= 0 || nseq <= 0 || !plan_saved(d, T, nseq, true, s)) return (size_t)-1;
+  return s.keys;
+}
+
+extern "C" size_t snx_model_bwd_workspace_bytes(const snx_model_desc* d, int32_t T, int32_t nseq, int32_t max_seqlen) {
+  if (!desc_ok(d) || T <= 0 || nseq <= 0 || max_seqlen <= 0) return 0;
   BwdPlan p;
-  plan_bwd(d, T, p);
+  plan_bwd(d, T, nseq, max_seqlen, p);
   return p.total;
 }
 
@@ -288,7 +295,7 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
   SavedPlan s;
   BwdPlan b;
   if (!plan_cache(d, c) || !plan_saved(d, T, nseq, true, s)) return SNX_E_SHAPE;
-  plan_bwd(d, T, b);
+  plan_bwd(d, T, nseq, max_seqlen, b);
   PIdx p{d->layers};
   const char* wc = (const char*)wcache;
   const char* sv = (const char*)saved;
@@ -305,25 +312,24 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
   // SPLADE tail + decoder (sparse routed), head
   { PROF(PC_SPLADE_BWD, 2.0 * 2.0 * nseq * V * H);
     RC(snx_splade_bwd(g_sparse, (const uint32_t*)(sv + s.keys), sv + s.hd, wc + c.emb, cu_seqlens, A, G(p.tok_emb()),
-                      G(p.dec_bias()), nullptr, T, nseq, max_seqlen, V, H, st)); }
+                      G(p.dec_bias()), sc + b.splade, T, nseq, max_seqlen, V, H, st)); }
   { PROF(PC_LN_BWD, TH * 6); RC(snx_gelu_ln_bwd(A, sv + s.dd, F(p.head_norm()), Bb, G(p.head_norm()), T, H, d->ln_eps, st)); }
   { PROF(PC_GEMM_TN, 2.0 * TH * H); RC(snx_gemm_tn_accum(Bb, sv + s.xf, G(p.head_dense()), T, H, H, st)); }
   { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(Bb, wc + c.dense_t, A, T, H, H, st)); }
-  { PROF(PC_LN_BWD, TH * 10); RC(snx_ln_bwd(A, hbuf(2 * L), F(p.final_norm()), dh, G(p.final_norm()), T, H, d->ln_eps, 1, st)); }
+  // every LayerNorm backward also emits bf16(dh) into A: the gradient of the next bf16 branch output
+  { PROF(PC_LN_BWD, TH * 12); RC(snx_ln_bwd(A, hbuf(2 * L), F(p.final_norm()), dh, A, G(p.final_norm()), T, H, d->ln_eps, 1, st)); }
 
   for (int l = L - 1; l >= 0; --l) {
     const bool global = (l % d->global_every) == 0;
     const double attn_keys = global ? max_seqlen : (2 * d->window + 1 < max_seqlen ? 2 * d->window + 1 : max_seqlen);
     // ---- MLP:  h[2l+2] = h[2l+1] + Wo( gelu(a) * g ),  [a|g] = Wi( LN(h[2l+1]) )
-    { PROF(PC_CAST, TH * 6); RC(snx_cast_bf16(dh, A, (int64_t)T * H, st)); }          // grad of the bf16 branch output
     { PROF(PC_GEMM_TN, 2.0 * TH * I); RC(snx_gemm_tn_accum(A, sv + s.y[l], G(p.wo_mlp(l)), T, H, I, st)); }
     { PROF(PC_GEMM_NT, 2.0 * TH * I); RC(snx_gemm_nt_bf16(A, wc + c.wom_t[l], Cc, T, I, H, st)); }   // dy [T,I]
     { PROF(PC_GEGLU, (double)T * I * 10); RC(snx_geglu_bwd(sv + s.u[l], Cc, Wd, T, I, st)); }        // du [T,2I]
     { PROF(PC_GEMM_TN, 2.0 * TH * 2 * I); RC(snx_gemm_tn_accum(Wd, sv + s.x_mlp[l], G(p.wi(l)), T, 2 * I, H, st)); }
     { PROF(PC_GEMM_NT, 2.0 * TH * 2 * I); RC(snx_gemm_nt_bf16(Wd, wc + c.wi_t[l], A, T, H, 2 * I, st)); }   // dx [T,H]
-    { PROF(PC_LN_BWD, TH * 14); RC(snx_ln_bwd(A, hbuf(2 * l + 1), F(p.mlp_norm(l)), dh, G(p.mlp_norm(l)), T, H, d->ln_eps, 0, st)); }
+    { PROF(PC_LN_BWD, TH * 16); RC(snx_ln_bwd(A, hbuf(2 * l + 1), F(p.mlp_norm(l)), dh, A, G(p.mlp_norm(l)), T, H, d->ln_eps, 0, st)); }
     // ---- attention:  h[2l+1] = h[2l] + Wo( attn( rope( Wqkv( LN(h[2l]) ) ) ) )
-    { PROF(PC_CAST, TH * 6); RC(snx_cast_bf16(dh, A, (int64_t)T * H, st)); }
     { PROF(PC_GEMM_TN, 2.0 * TH * H); RC(snx_gemm_tn_accum(A, sv + s.attn[l], G(p.wo(l)), T, H, H, st)); }
     { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(A, wc + c.wo_t[l], Bb, T, H, H, st)); }    // d(attn out)
     { PROF(PC_ATTN_BWD, 10.0 * TH * attn_keys);
@@ -334,8 +340,8 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
     { PROF(PC_GEMM_TN, 2.0 * TH * 3 * H); RC(snx_gemm_tn_accum(Wd, sv + s.x_attn[l], G(p.wqkv(l)), T, 3 * H, H, st)); }
     { PROF(PC_GEMM_NT, 2.0 * TH * 3 * H); RC(snx_gemm_nt_bf16(Wd, wc + c.wqkv_t[l], A, T, H, 3 * H, st)); }   // dx [T,H]
     if (l > 0) {
-      PROF(PC_LN_BWD, TH * 14);
-      RC(snx_ln_bwd(A, hbuf(2 * l), F(p.attn_norm(l)), dh, G(p.attn_norm(l)), T, H, d->ln_eps, 0, st));
+      PROF(PC_LN_BWD, TH * 16);
+      RC(snx_ln_bwd(A, hbuf(2 * l), F(p.attn_norm(l)), dh, A, G(p.attn_norm(l)), T, H, d->ln_eps, 0, st));
     } else {
       PROF(PC_CAST, TH * 10);
       hipLaunchKernelGGL(add_bf16_into_f32_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dh, (const bf16_t*)A, n4);

@@ -166,6 +166,11 @@ __device__ __forceinline__ float splade_coef(float g, uint32_t key) {
   return x > 0.f ? rbf(g / (1.0f + x)) : 0.f;
 }
 
+// Both kernels walk the non-zero coefficients of 64 (b or v) entries held one per lane; the
+// gathers are issued in batches of GB rows so that GB independent loads per wave are in flight
+// (a one-at-a-time loop is latency-bound: ~1 us per dependent row fetch).
+#define GB 8
+
 template <int NV>
 __global__ __launch_bounds__(256) void splade_bwd_dw_kernel(const float* __restrict__ g,
                                                             const uint32_t* __restrict__ keys,
@@ -190,23 +195,35 @@ __global__ __launch_bounds__(256) void splade_bwd_dw_kernel(const float* __restr
         c = splade_coef(g[(long)b * V + v], key);
         trow = cu_seqlens[b] + (int)(0xFFFFu - (key & 0xFFFFu));
       }
-      const unsigned long long live = __ballot(c != 0.f);
       bsum += c;
-      unsigned long long m = live;
+      unsigned long long m = __ballot(c != 0.f);
       while (m) {
-        const int src = __builtin_ctzll(m);
-        m &= m - 1;
-        const float cb = __shfl(c, src, 64);
-        const int tb = __shfl(trow, src, 64);
-        const bf16_t* hrow = Hd + (long)tb * H;
+        float cb[GB];
+        bf16x4 hv[GB][NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          const bf16x4 h4 = *(const bf16x4*)(hrow + (i * 64 + lane) * 4);
-          acc[i][0] += cb * bf2f(h4[0]);
-          acc[i][1] += cb * bf2f(h4[1]);
-          acc[i][2] += cb * bf2f(h4[2]);
-          acc[i][3] += cb * bf2f(h4[3]);
+        for (int u = 0; u < GB; ++u) {
+          cb[u] = 0.f;
+          if (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            cb[u] = __shfl(c, src, 64);
+            const bf16_t* hrow = Hd + (long)__shfl(trow, src, 64) * H;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) hv[u][i] = *(const bf16x4*)(hrow + (i * 64 + lane) * 4);
+          } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) hv[u][i] = (bf16x4){0, 0, 0, 0};
+          }
         }
+#pragma unroll
+        for (int u = 0; u < GB; ++u)
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            acc[i][0] += cb[u] * bf2f(hv[u][i][0]);
+            acc[i][1] += cb[u] * bf2f(hv[u][i][1]);
+            acc[i][2] += cb[u] * bf2f(hv[u][i][2]);
+            acc[i][3] += cb[u] * bf2f(hv[u][i][3]);
+          }
       }
     }
     bsum = wave_sum(bsum);
@@ -220,56 +237,132 @@ __global__ __launch_bounds__(256) void splade_bwd_dw_kernel(const float* __restr
   }
 }
 
-// One workgroup = (sequence, CW-column slice of H).  dH slice lives in LDS as fp32 [slen][CW].
-__global__ __launch_bounds__(512) void splade_bwd_dh_kernel(const float* __restrict__ g,
-                                                            const uint32_t* __restrict__ keys,
-                                                            const bf16_t* __restrict__ W,
-                                                            const int32_t* __restrict__ cu_seqlens,
-                                                            bf16_t* __restrict__ dHd, int V, int H, int CW,
-                                                            int max_rows) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int seq = blockIdx.y, c0 = blockIdx.x * CW;
-  const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// dHd: LDS float atomics run at only ~1 lane per 2-3 cycles on this chip (measured: 16 ms per
+// document pass when the [S][H] slab was accumulated with ds_add_f32), so the routed entries are
+// first BUCKETED by target row (counting sort per sequence, integer LDS atomics on S counters
+// only), then one wave per token row gathers its W rows and accumulates in registers -- no float
+// atomics, every dHd row written exactly once (rows without entries get zeros).
+__global__ __launch_bounds__(1024) void splade_bucket_kernel(const float* __restrict__ g,
+                                                             const uint32_t* __restrict__ keys,
+                                                             const int32_t* __restrict__ cu_seqlens,
+                                                             int32_t* __restrict__ list_v, float* __restrict__ list_c,
+                                                             int32_t* __restrict__ row_off, int V, int max_rows) {
+  extern __shared__ __attribute__((aligned(16))) int32_t smi[];
+  int32_t* cnt = smi;                    // [max_rows]
+  int32_t* off = smi + max_rows;         // [max_rows + 1]
+  int32_t* fill = off + max_rows + 1;    // [max_rows]
+  const int seq = blockIdx.x;
+  const int slen = cu_seqlens[seq + 1] - cu_seqlens[seq];
   const int rows = slen < max_rows ? slen : max_rows;
-  for (int i = threadIdx.x; i < rows * CW; i += 512) sm[i] = 0.f;
+  for (int i = threadIdx.x; i < max_rows; i += blockDim.x) { cnt[i] = 0; fill[i] = 0; }
   __syncthreads();
   const float* gs = g + (long)seq * V;
   const uint32_t* ks = keys + (long)seq * V;
-  const int per_lane = CW / 64;                        // 1, 2, 4 or 8 columns per lane
-  for (int v0 = wave * 64; v0 < V; v0 += 8 * 64) {
-    const int v = v0 + lane;
-    float c = 0.f;
-    int row = 0;
-    if (v < V) {
-      const uint32_t key = ks[v];
-      c = splade_coef(gs[v], key);
-      row = (int)(0xFFFFu - (key & 0xFFFFu));
-      if (row >= rows) c = 0.f;                        // cannot happen for a valid key; keeps LDS in bounds
-    }
-    unsigned long long m = __ballot(c != 0.f);
-    while (m) {
-      const int src = __builtin_ctzll(m);
-      m &= m - 1;
-      const float cb = __shfl(c, src, 64);
-      const int rb = __shfl(row, src, 64);
-      const bf16_t* wrow = W + (long)(v0 + src) * H + c0 + lane * per_lane;
-      float* drow = sm + rb * CW + lane * per_lane;
-      for (int e = 0; e < per_lane; ++e) atomicAdd(drow + e, cb * bf2f(wrow[e]));
-    }
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    const uint32_t key = ks[v];
+    const int row = (int)(0xFFFFu - (key & 0xFFFFu));
+    if (splade_coef(gs[v], key) != 0.f && row < rows) atomicAdd(&cnt[row], 1);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < rows * CW; i += 512) {
-    const int r = i / CW, c = i % CW;
-    dHd[(long)(s0 + r) * H + c0 + c] = f2bf(sm[i]);
+  if (threadIdx.x < 64) {                // exclusive scan of cnt[0..rows) by one wave
+    const int lane = threadIdx.x;
+    const int per = (rows + 63) / 64;
+    int local = 0;
+    for (int i = 0; i < per; ++i) {
+      const int r = lane * per + i;
+      if (r < rows) local += cnt[r];
+    }
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    int run = incl - local;
+    for (int i = 0; i < per; ++i) {
+      const int r = lane * per + i;
+      if (r < rows) { off[r] = run; run += cnt[r]; }
+    }
+    if (lane == 63) off[rows] = incl;
   }
+  __syncthreads();
+  int32_t* lv = list_v + (long)seq * V;
+  float* lc = list_c + (long)seq * V;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    const uint32_t key = ks[v];
+    const int row = (int)(0xFFFFu - (key & 0xFFFFu));
+    const float c = splade_coef(gs[v], key);
+    if (c != 0.f && row < rows) {
+      const int slot = off[row] + atomicAdd(&fill[row], 1);
+      lv[slot] = v;
+      lc[slot] = c;
+    }
+  }
+  for (int r = threadIdx.x; r <= rows; r += blockDim.x) row_off[(long)seq * (max_rows + 1) + r] = off[r];
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void splade_bwd_dh_rows_kernel(const int32_t* __restrict__ list_v,
+                                                                 const float* __restrict__ list_c,
+                                                                 const int32_t* __restrict__ row_off,
+                                                                 const bf16_t* __restrict__ W,
+                                                                 const int32_t* __restrict__ cu_seqlens,
+                                                                 bf16_t* __restrict__ dHd, int V, int H, int max_rows) {
+  const int seq = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
+  if (row >= slen) return;
+  f32x4 acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (row < max_rows) {
+    const int32_t* ro = row_off + (long)seq * (max_rows + 1);
+    const int beg = ro[row], end = ro[row + 1];
+    const int32_t* lv = list_v + (long)seq * V;
+    const float* lc = list_c + (long)seq * V;
+    for (int e0 = beg; e0 < end; e0 += 64) {
+      const int e = e0 + lane;
+      const int vv = e < end ? lv[e] : 0;
+      const float cc = e < end ? lc[e] : 0.f;
+      const int n = min(64, end - e0);
+      for (int u0 = 0; u0 < n; u0 += GB) {
+        float cb[GB];
+        bf16x4 wv[GB][NV];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int src = u0 + u;                               // wave-uniform
+          cb[u] = src < n ? __shfl(cc, src, 64) : 0.f;
+          const bf16_t* wrow = W + (long)__shfl(vv, src < n ? src : 0, 64) * H;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) wv[u][i] = *(const bf16x4*)(wrow + (i * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u)
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            acc[i][0] += cb[u] * bf2f(wv[u][i][0]);
+            acc[i][1] += cb[u] * bf2f(wv[u][i][1]);
+            acc[i][2] += cb[u] * bf2f(wv[u][i][2]);
+            acc[i][3] += cb[u] * bf2f(wv[u][i][3]);
+          }
+      }
+    }
+  }
+  bf16_t* out = dHd + (long)(s0 + row) * H;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    *(bf16x4*)(out + (i * 64 + lane) * 4) = (bf16x4){f2bf(acc[i][0]), f2bf(acc[i][1]), f2bf(acc[i][2]), f2bf(acc[i][3])};
+}
+
+extern "C" size_t snx_splade_bwd_scratch_bytes(int32_t nseq, int32_t max_seqlen, int32_t V) {
+  return (size_t)nseq * V * 8 + (size_t)nseq * (max_seqlen + 1) * 4 + 256;
 }
 
 extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* Hd, const void* W,
-                              const int32_t* cu_seqlens, void* dHd, float* gradE, float* gradb, void* reserved,
+                              const int32_t* cu_seqlens, void* dHd, float* gradE, float* gradb, void* scratch,
                               int32_t T, int32_t nseq, int32_t max_seqlen, int32_t V, int32_t H, hipStream_t st) {
-  (void)reserved;
-  if (!g || !keys || !Hd || !W || !cu_seqlens || !dHd || !gradE || !gradb) return SNX_E_ARG;
+  if (!g || !keys || !Hd || !W || !cu_seqlens || !dHd || !gradE || !gradb || !scratch) return SNX_E_ARG;
   if (T <= 0 || nseq <= 0 || V <= 0 || max_seqlen <= 0 || H <= 0 || (H % 256) || H > 1024) return SNX_E_SHAPE;
   const int blocks = 2048;
   switch (H / 256) {
@@ -279,14 +372,25 @@ extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* 
     default: hipLaunchKernelGGL(splade_bwd_dw_kernel<4>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
   }
   SNX_CHECK_LAUNCH();
-  // column-slice width: largest of {512,256,128,64} dividing H whose fp32 [max_seqlen][CW] slab fits 128 KiB
-  int CW = 512;
-  while (CW > 64 && ((size_t)max_seqlen * CW * 4 > 128 * 1024 || (H % CW) != 0)) CW >>= 1;
-  if ((size_t)max_seqlen * CW * 4 > 160 * 1024 - 1024 || (H % CW) != 0) return SNX_E_SHAPE;
-  const size_t lds = (size_t)max_seqlen * CW * 4;
-  hipFuncSetAttribute((const void*)splade_bwd_dh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(splade_bwd_dh_kernel, dim3(H / CW, nseq), dim3(512), lds, st, g, keys, (const bf16_t*)W,
-                     cu_seqlens, (bf16_t*)dHd, V, H, CW, max_seqlen);
+  // dHd: bucket by row, then one wave per token row
+  if (max_seqlen > 8192) return SNX_E_SHAPE;
+  char* sc = (char*)scratch;
+  int32_t* list_v = (int32_t*)sc;
+  float* list_c = (float*)(sc + (size_t)nseq * V * 4);
+  int32_t* row_off = (int32_t*)(sc + (size_t)nseq * V * 8);
+  const size_t lds = (size_t)(3 * max_seqlen + 1) * 4;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)splade_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(splade_bucket_kernel, dim3(nseq), dim3(1024), lds, st, g, keys, cu_seqlens, list_v, list_c,
+                     row_off, V, max_seqlen);
+  SNX_CHECK_LAUNCH();
+  const dim3 grid(cdiv(max_seqlen, 4), nseq);
+  switch (H / 256) {
+    case 1: hipLaunchKernelGGL(splade_bwd_dh_rows_kernel<1>, grid, dim3(256), 0, st, list_v, list_c, row_off, (const bf16_t*)W, cu_seqlens, (bf16_t*)dHd, V, H, max_seqlen); break;
+    case 2: hipLaunchKernelGGL(splade_bwd_dh_rows_kernel<2>, grid, dim3(256), 0, st, list_v, list_c, row_off, (const bf16_t*)W, cu_seqlens, (bf16_t*)dHd, V, H, max_seqlen); break;
+    case 3: hipLaunchKernelGGL(splade_bwd_dh_rows_kernel<3>, grid, dim3(256), 0, st, list_v, list_c, row_off, (const bf16_t*)W, cu_seqlens, (bf16_t*)dHd, V, H, max_seqlen); break;
+    default: hipLaunchKernelGGL(splade_bwd_dh_rows_kernel<4>, grid, dim3(256), 0, st, list_v, list_c, row_off, (const bf16_t*)W, cu_seqlens, (bf16_t*)dHd, V, H, max_seqlen); break;
+  }
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }

@@ -28,7 +28,7 @@ SIGNATURES = {
     "snx_ln_fwd": (I32, [P, P, P, I32, I32, F32, P]),
     "snx_embed_ln_fwd": (I32, [P, P, P, P, P, I32, I32, F32, P]),
     "snx_gelu_ln_fwd": (I32, [P, P, P, I32, I32, F32, P]),
-    "snx_ln_bwd": (I32, [P, P, P, P, P, I32, I32, F32, I32, P]),
+    "snx_ln_bwd": (I32, [P, P, P, P, P, P, I32, I32, F32, I32, P]),
     "snx_embed_ln_bwd": (I32, [P, P, P, P, P, P, I32, I32, F32, I32, P]),
     "snx_gelu_ln_bwd": (I32, [P, P, P, P, P, I32, I32, F32, P]),
     "snx_rope_inplace": (I32, [P, P, P, I32, I32, I32, P]),
@@ -43,7 +43,9 @@ SIGNATURES = {
     "snx_loss_fwd": (I32, [P, P, P, P, P, P, P, P, P, P]),
     "snx_loss_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P]),
     "snx_model_workspace_bytes": (SZ, [P, I32, I32, I32]),
-    "snx_model_bwd_workspace_bytes": (SZ, [P, I32, I32]),
+    "snx_model_bwd_workspace_bytes": (SZ, [P, I32, I32, I32]),
+    "snx_splade_bwd_scratch_bytes": (SZ, [I32, I32, I32]),
+    "snx_model_keys_offset": (SZ, [P, I32, I32]),
     "snx_weight_cache_bytes": (SZ, [P]),
     "snx_weight_cache_refresh": (I32, [P, P, P, P]),
     "snx_model_forward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P]),

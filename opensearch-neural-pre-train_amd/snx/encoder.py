@@ -173,6 +173,14 @@ class EncoderRuntime:
         aux = (ids, mask, cu, pos, rg, rl, T, B, S)
         return sparse, tw, saved, aux
 
+    def routing_rows(self, saved: torch.Tensor, aux) -> torch.Tensor:
+        """Arg-max sequence position per (sequence, vocab) entry chosen by the fused max-pool
+        ([B, V] int64; entries whose pooled value is 0 carry no gradient)."""
+        T, B = aux[6], aux[7]
+        off = fn("snx_model_keys_offset")(C.byref(self._desc), T, B)
+        keys = saved[off:off + B * self.geom.vocab_size * 4].view(torch.int32).view(B, -1).to(torch.int64) & 0xFFFFFFFF
+        return 0xFFFF - (keys & 0xFFFF)
+
     def backward_impl(self, saved: torch.Tensor, aux, g_sparse: torch.Tensor):
         ids, mask, cu, pos, rg, rl, T, B, S = aux
         dev = self._device()
@@ -190,7 +198,7 @@ class EncoderRuntime:
                 grads.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             ret = grads
-        nbytes = fn("snx_model_bwd_workspace_bytes")(C.byref(self._desc), T, B)
+        nbytes = fn("snx_model_bwd_workspace_bytes")(C.byref(self._desc), T, B, S)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         check(fn("snx_model_backward")(C.byref(self._desc), self._param_ptrs(), self._grad_ptrs(grads),
                                        _p(self._weights()), _p(ids), _p(mask), _p(cu), _p(pos), _p(rg), _p(rl),
@@ -209,6 +217,7 @@ class _SpladeEncodeFn(torch.autograd.Function):
     def forward(ctx, rt: EncoderRuntime, input_ids, attention_mask, *params):
         sparse, tw, saved, aux = rt.forward_impl(input_ids, attention_mask, save=True)
         ctx.rt, ctx.saved_arena, ctx.aux = rt, saved, aux
+        rt.last_ctx = (saved, aux)          # debugging / parity tests: routing of the latest forward
         ctx.mark_non_differentiable(tw)
         return sparse, tw
 

@@ -119,12 +119,15 @@ def gelu_ln_fwd(d: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
 
 
 def ln_bwd(dy: torch.Tensor, h: torch.Tensor, w: torch.Tensor, dh: torch.Tensor, dw: torch.Tensor, eps: float,
-           overwrite: bool = False) -> None:
-    """dh (+)= LN_bwd(dy; h, w);  dw += sum_t dy * xhat."""
+           overwrite: bool = False, dh_bf16: Optional[torch.Tensor] = None) -> None:
+    """dh (+)= LN_bwd(dy; h, w);  dw += sum_t dy * xhat;  dh_bf16 (optional) = bf16(dh)."""
     _chk(h, torch.float32, "h"); T, H = h.shape
     _chk(dy, BF16, "dy", (T, H)); _chk(w, torch.float32, "w", (H,))
     _chk(dh, torch.float32, "dh", (T, H)); _chk(dw, torch.float32, "dw", (H,))
-    check(fn("snx_ln_bwd")(_p(dy), _p(h), _p(w), _p(dh), _p(dw), T, H, eps, int(overwrite), _stream()), "snx_ln_bwd")
+    if dh_bf16 is not None:
+        _chk(dh_bf16, BF16, "dh_bf16", (T, H))
+    check(fn("snx_ln_bwd")(_p(dy), _p(h), _p(w), _p(dh), _p(dh_bf16), _p(dw), T, H, eps, int(overwrite), _stream()),
+          "snx_ln_bwd")
 
 
 def embed_ln_bwd(dh: torch.Tensor, ids: torch.Tensor, E: torch.Tensor, w: torch.Tensor, gradE: torch.Tensor,

@@ -271,12 +271,18 @@ def encoder_logits(params: Dict[str, torch.Tensor], cfg: EncoderConfig, input_id
     return logits
 
 
-def splade_forward(params, cfg, input_ids, attention_mask, mode: str = "fp32"):
+def splade_forward(params, cfg, input_ids, attention_mask, mode: str = "fp32", route_rows=None):
     """SPLADEModernBERT.forward (ref:src/model/splade_modern.py:50-88) ->
-    (sparse_repr [B, V] fp32, token_weights [B, S] fp32)."""
+    (sparse_repr [B, V] fp32, token_weights [B, S] fp32).
+    ``route_rows`` [B, V] (test-only): take the value at the given sequence position instead of
+    the max -- pins the max-pool routing so that gradients of two bf16 implementations can be
+    compared tightly (a 1-ulp logit difference otherwise re-routes tied entries)."""
     logits = encoder_logits(params, cfg, input_ids, attention_mask, mode)
     s = torch.log1p(torch.relu(logits).float())          # log1p autocasts to fp32
     s = s * attention_mask.unsqueeze(-1).float()
+    if route_rows is not None:
+        sparse_repr = torch.gather(s, 1, route_rows.clamp(0, s.shape[1] - 1).unsqueeze(1)).squeeze(1)
+        return sparse_repr, s.max(dim=-1).values
     sparse_repr = s.max(dim=1).values
     token_weights = s.max(dim=-1).values
     return sparse_repr, token_weights

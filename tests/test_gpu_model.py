@@ -71,14 +71,14 @@ def _grad_stats(got, ref):
     return cos, rel
 
 
-@pytest.mark.parametrize("k,margin,Sq,Sd,cos_min,rel_max", [(1, 0.0, 8, 12, 0.999, 3e-2), (2, 0.05, 8, 12, 0.999, 3e-2),
-                                                            (1, 0.0, 40, 150, 0.98, 0.2), (2, 0.05, 40, 150, 0.98, 0.2)])
+@pytest.mark.parametrize("k,margin,Sq,Sd,cos_min,rel_max", [(1, 0.0, 8, 12, 0.99, 0.15), (1, 0.0, 40, 150, 0.98, 0.2),
+                                                            (2, 0.05, 40, 150, 0.98, 0.2)])
 def test_small_model_forward_backward_vs_oracle(dev, k, margin, Sq, Sd, cos_min, rel_max):
     """Gradient tolerance: the max-pool routes each (b, v) gradient to ONE sequence position; bf16
     logits tie or nearly tie often, so a 1-ulp accumulation-order flip re-routes that entry.  With
-    short sequences flips are rare and the tight bound (cos >= 0.999, rel-L2 <= 3e-2) holds; at
-    q40/d150 the oracle's OWN bf16-vs-fp32 gradients agree only to cos ~0.99 / rel ~0.14 (measured,
-    see DESIGN.md), so that case is held to cos >= 0.98 / rel <= 0.2 and the numbers are reported."""
+    free routing the oracle's OWN bf16-vs-fp32 gradients agree only to cos ~0.99 / rel ~0.14 at
+    q40/d150 (measured), so these cases are held to cos >= 0.98 / rel <= 0.2 and the
+    numbers are reported; the tight bound is enforced by the pinned-routing test below."""
     from oracle import splade_oracle as O
     from src.model.losses import SPLADELossV33
     cfg = _small_cfg()
@@ -140,6 +140,47 @@ def test_small_model_forward_backward_vs_oracle(dev, k, margin, Sq, Sd, cos_min,
     rep["worst_grad"] = worst
     _report(f"small_fwd_bwd_k{k}_q{Sq}_d{Sd}", rep)
     bad = {n_: v for n_, v in rep["grads"].items() if v[0] < cos_min or v[1] > rel_max}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("k,margin,Sq,Sd", [(1, 0.0, 40, 150), (2, 0.05, 24, 70)])
+def test_small_model_gradients_with_pinned_routing(dev, k, margin, Sq, Sd):
+    """Backward parity at the survey's tight bound (cos >= 0.999, rel-L2 <= 2e-2 per tensor): the
+    oracle (emulated bf16) back-propagates through the SAME max-pool routing the HIP forward chose
+    (read back from the saved arg-max keys), which removes the only discontinuity of the path."""
+    from oracle import splade_oracle as O
+    from src.model.losses import SPLADELossV33
+    cfg = _small_cfg()
+    params = O.perturb_params(O.init_params(cfg, seed=3), seed=4, scale=2.0, bias_mean=-0.1)
+    gen = torch.Generator().manual_seed(300 + k)
+    b = O.synth_batch(6, Sq, Sd, cfg, gen, k=k, ragged=True, teacher=margin > 0)
+    lc = O.LossConfig(lambda_q=0.01, lambda_d=0.003, temperature=20.0, flops_warmup_steps=50,
+                      lambda_initial_ratio=0.1, lambda_margin_mse=margin)
+    model = _build_model(cfg, params, dev)
+    loss_fn = SPLADELossV33(lambda_q=lc.lambda_q, lambda_d=lc.lambda_d, temperature=lc.temperature,
+                            flops_warmup_steps=lc.flops_warmup_steps, lambda_initial_ratio=lc.lambda_initial_ratio,
+                            lambda_margin_mse=margin).to(dev)
+    D = lambda t: t.to(dev) if torch.is_tensor(t) else t   # noqa: E731
+    rows, outs = {}, {}
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        for tag in ("query", "positive", "negative"):
+            outs[tag], _ = model(D(b[tag + "_input_ids"]), D(b[tag + "_attention_mask"]))
+            rows[tag] = model.runtime.routing_rows(*model.runtime.last_ctx).cpu()
+        n3 = outs["negative"].view(6, k, -1) if k > 1 else outs["negative"]
+        loss, _ = loss_fn(anchor_repr=outs["query"], positive_repr=outs["positive"], negative_repr=n3, global_step=20,
+                          teacher_pos_scores=D(b.get("teacher_pos_scores")), teacher_neg_scores=D(b.get("teacher_neg_scores")))
+    loss.backward()
+    leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    o = {t: O.splade_forward(leaves, cfg, b[t + "_input_ids"], b[t + "_attention_mask"], "bf16", route_rows=rows[t])[0]
+         for t in ("query", "positive", "negative")}
+    on3 = o["negative"].view(6, k, -1) if k > 1 else o["negative"]
+    oloss, _ = O.loss_v33(lc, o["query"], o["positive"], on3, 20, b.get("teacher_pos_scores"), b.get("teacher_neg_scores"), "bf16")
+    oloss.backward()
+    assert float(loss) == pytest.approx(float(oloss), rel=5e-3)
+    stats = {name: _grad_stats(prm.grad.cpu(), leaves[name].grad) for name, prm in model.named_parameters()}
+    worst = min(stats.items(), key=lambda kv: kv[1][0])
+    _report(f"small_pinned_routing_k{k}", {"worst": [worst[0], *worst[1]], "max_rel": max(v[1] for v in stats.values())})
+    bad = {n_: v for n_, v in stats.items() if v[0] < 0.999 or v[1] > 2e-2}
     assert not bad, bad
 
 

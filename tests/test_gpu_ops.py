@@ -133,8 +133,10 @@ def test_layernorm_bwd(dev, T, H):
     assert torch.allclose(dw, wl.grad, rtol=1e-3, atol=1e-4)
     dh2 = torch.full_like(dh0, float("nan"))
     dw2 = torch.zeros(H, device=dev)
-    ops.ln_bwd(dy, h, w, dh2, dw2, 1e-5, overwrite=True)
+    dhb = torch.empty(T, H, dtype=BF16, device=dev)
+    ops.ln_bwd(dy, h, w, dh2, dw2, 1e-5, overwrite=True, dh_bf16=dhb)
     assert torch.allclose(dh2, hl.grad, rtol=1e-4, atol=1e-5)
+    assert torch.equal(dhb, dh2.to(BF16))
 
 
 def test_embed_ln_bwd(dev):
@@ -365,8 +367,9 @@ def test_splade_bwd(dev, B, S, V, H):
     gE0 = torch.randn(V, H, generator=g).to(dev)
     gb0 = torch.randn(V, generator=g).to(dev)
     gE, gb = gE0.clone(), gb0.clone()
-    check(fn("snx_splade_bwd")(_p(gs.to(dev)), _p(keys), _p(hdd), _p(Wd), _p(cud), _p(dHd), _p(gE), _p(gb), None,
-                               T, B, S, V, H, _stream()), "snx_splade_bwd")
+    scratch = torch.empty(fn("snx_splade_bwd_scratch_bytes")(B, S, V), dtype=torch.uint8, device=dev)
+    check(fn("snx_splade_bwd")(_p(gs.to(dev)), _p(keys), _p(hdd), _p(Wd), _p(cud), _p(dHd), _p(gE), _p(gb),
+                               _p(scratch), T, B, S, V, H, _stream()), "snx_splade_bwd")
     # dense reference through autograd on the bf16 logits
     hl = hdd.float().requires_grad_(True)
     Wl = Wd.float().requires_grad_(True)
