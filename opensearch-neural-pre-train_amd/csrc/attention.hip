@@ -190,24 +190,6 @@ extern "C" int snx_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const in
 // over its row index) is staged twice, once per swizzle (k_off image for ds_read_b128 rows,
 // v_off image for ds_read_b64_tr_b16).
 // ==========================================================================================
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                  float* __restrict__ delta, int T, int heads) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long)T * heads) return;
-  const int head = gid % heads;
-  const long t = gid / heads;
-  const bf16_t* po = o + (t * heads + head) * 64;
-  const bf16_t* pd = dout + (t * heads + head) * 64;
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const bf16x8 a = *(const bf16x8*)(po + c * 8), b = *(const bf16x8*)(pd + c * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(b[e]);
-  }
-  delta[(long)head * T + t] = s;
-}
-
 // stage a 64x64 bf16 tile twice: row image (k_off) and transposed-read image (v_off)
 __device__ __forceinline__ void stage_dual(const bf16_t* __restrict__ base, long row_stride, int r0g, int rmax,
                                            char* lds_row, char* lds_tr) {
@@ -235,9 +217,9 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int dt, int c, int l
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
-    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-    const float* __restrict__ delta, const int32_t* __restrict__ cu_seqlens, const int64_t* __restrict__ mask,
-    bf16_t* __restrict__ dqkv, int T, int heads, int window, float scale) {
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+    const float* __restrict__ lse, float* __restrict__ delta, const int32_t* __restrict__ cu_seqlens,
+    const int64_t* __restrict__ mask, bf16_t* __restrict__ dqkv, int T, int heads, int window, float scale) {
   __shared__ __attribute__((aligned(16))) char sKr[64 * 128];
   __shared__ __attribute__((aligned(16))) char sKt[64 * 128];
   __shared__ __attribute__((aligned(16))) char sVr[64 * 128];
@@ -262,7 +244,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     dof[c] = *(const bf16x8*)(dout + (long)(s0 + qrow) * H + head * 64 + c * 32 + g * 8);
   }
   const float lse_q = lse[(long)head * T + s0 + qrow];
-  const float dl_q = delta[(long)head * T + s0 + qrow];
+  // delta_q = sum_d dO[q,d] * O[q,d]: this lane holds 16 of the 64 d's; the 4 lane groups sum up.
+  // Written out for the dK/dV pass that follows on the same stream.
+  float dl_q = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const bf16x8 of = *(const bf16x8*)(out + (long)(s0 + qrow) * H + head * 64 + c * 32 + g * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl_q += bf2f(of[e]) * bf2f(dof[c][e]);
+  }
+  dl_q += __shfl_xor(dl_q, 16, 64);
+  dl_q += __shfl_xor(dl_q, 32, 64);
+  if (g == 0 && qpos < slen) delta[(long)head * T + s0 + qpos] = dl_q;
 
   int j_lo = 0, j_hi = (slen - 1) >> 6;
   if (window >= 0) {
@@ -432,12 +425,10 @@ extern "C" int snx_attn_bwd(const void* qkv, const void* out, const void* dout, 
                             int32_t window, hipStream_t st) {
   if (!qkv || !out || !dout || !lse || !cu_seqlens || !mask || !delta_scratch || !dqkv) return SNX_E_ARG;
   if (T <= 0 || nseq <= 0 || max_seqlen <= 0 || heads <= 0 || head_dim != 64) return SNX_E_SHAPE;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)T * heads, 256)), dim3(256), 0, st, (const bf16_t*)out,
-                     (const bf16_t*)dout, delta_scratch, T, heads);
-  SNX_CHECK_LAUNCH();
   dim3 grid(cdiv(max_seqlen, 64), heads, nseq);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
-                     delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, T, heads, window, 0.125f);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                     (const bf16_t*)dout, lse, delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, T, heads, window,
+                     0.125f);
   SNX_CHECK_LAUNCH();
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
                      delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, T, heads, window, 0.125f);

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
 #pragma unroll
     for (int j = 0; j < Core::NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
-  // transposed accumulators: this lane owns columns col..col+3 of row `row`
+  // transposed accumulators: this lane owns columns col..col+3 of row `row` (8-B / 16-B accesses)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 #pragma unroll
@@ -173,7 +173,9 @@ extern "C" int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32
   if (!dY || !X || !dW) return SNX_E_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128)) return SNX_E_SHAPE;
   const int tiles = (N / 128) * (K / 128);
-  int splits = cdiv(304, tiles);            // ~1.2 blocks per CU: fewer partial tiles -> fewer float atomics
+  // token-range splits: fill (at most) the 512 resident workgroup slots (2 x 64 KiB LDS per CU on
+  // 256 CUs); more splits than that only add float-atomic traffic
+  int splits = 512 / tiles;
   const int max_splits = cdiv(M, 256);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

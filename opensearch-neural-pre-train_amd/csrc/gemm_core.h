@@ -47,6 +47,33 @@ struct GemmCore {
     return *(const bf16x8*)(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
   }
 
+  // multiply-accumulate one staged 64-deep K-tile (A tile at `cur`, B tile at cur + A_BYTES)
+  template <bool TRANSPOSED>
+  static __device__ __forceinline__ void compute_step(const char* cur, int wm, int wn, int lane,
+                                                      f32x4 (&acc)[MI][NI]) {
+    const char* ta = cur;
+    const char* tb = cur + A_BYTES;
+    // all 2*(MI+NI) fragment reads are issued up front: the k=32..63 reads are still in flight
+    // while the k=0..31 MFMAs run (the compiler's counted lgkmcnt waits do the rest)
+    bf16x8 a[2][MI], b[2][NI];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int chunk = kk * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[kk][i] = frag(ta, wm * WTM + i * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[kk][j] = frag(tb, wn * WTN + j * 16 + (lane & 15), chunk);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = TRANSPOSED ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+  }
+
   // acc must be zero-initialised (or hold the running sum) by the caller.
   // TRANSPOSED=false: acc[i][j][r] = C[wm*WTM + i*16 + 4g + r][wn*WTN + j*16 + li]   (g = lane>>4, li = lane&15)
   // TRANSPOSED=true : acc[i][j][r] = C[wm*WTM + i*16 + li][wn*WTN + j*16 + 4g + r]   -- each lane owns 4
@@ -70,23 +97,7 @@ struct GemmCore {
         stage<BM>(A, lda, m0, M, (kt + 1) * BK, nxt, wave, lane);
         stage<BN>(B, ldb, n0, N, (kt + 1) * BK, nxt + A_BYTES, wave, lane);
       }
-      const char* ta = cur;
-      const char* tb = cur + A_BYTES;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 a[MI], b[NI];
-        const int chunk = kk * 4 + (lane >> 4);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = frag(ta, wm * WTM + i * 16 + (lane & 15), chunk);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) b[j] = frag(tb, wn * WTN + j * 16 + (lane & 15), chunk);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[i][j] = TRANSPOSED ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0)
-                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
+      compute_step<TRANSPOSED>(cur, wm, wn, lane, acc);
     }
   }
 
