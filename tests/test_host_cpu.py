@@ -1,0 +1,273 @@
+"""CPU-only checks: the C ABI (library loads, exports every symbol of include/snx.h, argument
+validation without touching a GPU), the host-side mirror of the reference interface, and the
+multi-process (gloo, world_size 2) collectives used by the native data-parallel path."""
+import json
+import math
+import os
+import re
+import socket
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------- C ABI
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "snx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(snx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_header_symbol():
+    import snx
+    from snx import _lib
+    names = _header_functions()
+    assert len(names) >= 30
+    lib = snx.lib()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    # the ctypes table binds exactly the header's functions
+    assert sorted(_lib.SIGNATURES) == [n for n in names if n != "snx_model_desc"]
+    assert snx.verify_exports() == []
+    assert snx.fn("snx_version")() >= 1
+
+
+def test_shape_validation_happens_on_the_host():
+    """Mis-shaped calls are rejected before any launch (no GPU is needed to see the error code)."""
+    import ctypes as C
+    from snx import fn
+    from snx.encoder import EncoderGeometry
+    one = C.c_void_p(16)
+    assert fn("snx_gemm_nt_bf16")(one, one, one, 128, 128, 100, None) == -2          # K % 64 != 0
+    assert fn("snx_gemm_nt_bf16")(None, one, one, 128, 128, 128, None) == -3
+    assert fn("snx_gemm_tn_accum")(one, one, one, 128, 100, 128, None) == -2          # N % 128 != 0
+    assert fn("snx_ln_fwd")(one, one, one, 4, 100, 1e-5, None) == -2                  # H % 256 != 0
+    assert fn("snx_attn_fwd")(one, one, one, one, one, 64, 1, 64, 12, 32, -1, None) == -2   # head_dim != 64
+    d = EncoderGeometry().desc()
+    assert fn("snx_param_count")(C.byref(d)) == 137
+    assert fn("snx_weight_cache_bytes")(C.byref(d)) > 2 * 2 * 110_000_000
+    assert fn("snx_model_workspace_bytes")(C.byref(d), 64 * 256, 64, 1) > fn("snx_model_workspace_bytes")(C.byref(d), 64 * 256, 64, 0)
+    bad = EncoderGeometry(hidden_size=512, num_attention_heads=16).desc()            # head_dim 32
+    assert fn("snx_param_count")(C.byref(bad)) == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    from snx.encoder import EncoderGeometry
+    from src.model.losses import SPLADELossV33
+    from src.model.splade_modern import SPLADEModernBERT
+    g = dict(vocab_size=300, hidden_size=256, intermediate_size=128, num_hidden_layers=1, num_attention_heads=4,
+             pad_token_id=299)
+    m = SPLADEModernBERT(config=g)
+    ids = torch.zeros(2, 8, dtype=torch.long)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(ids, torch.ones_like(ids))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SPLADELossV33()(torch.rand(2, 10), torch.rand(2, 10), torch.rand(2, 10))
+    with pytest.raises(ValueError):
+        EncoderGeometry(hidden_size=512, num_attention_heads=16).check_supported()
+
+
+# ---------------------------------------------------------------------------------- host mirror
+def test_model_parameter_contract_full_geometry():
+    """138 state-dict keys / 137 parameters / 149,372,240 elements, reference names."""
+    from oracle import splade_oracle as O
+    from src.model.splade_modern import SPLADEModernBERT
+    import logging
+    logging.getLogger("src.model.splade_modern").setLevel(logging.ERROR)
+    m = SPLADEModernBERT()
+    names = [n for n, _ in m.named_parameters()]
+    assert names == O.param_names(O.EncoderConfig())
+    assert sum(p.numel() for p in m.parameters()) == 149_372_240
+    sd = m.state_dict()
+    assert len(sd) == 138 and "model.decoder.weight" in sd
+    assert m.model.decoder.weight is m.model.model.embeddings.tok_embeddings.weight
+    shapes = O.param_shapes(O.EncoderConfig())
+    assert all(tuple(sd[k].shape) == shapes[k] for k in names)
+    # optimizer grouping quirk: only decoder.bias escapes weight decay
+    from src.train.config.v33 import V33Config
+    from src.train.core.ddp_trainer import build_optimizer
+    opt = build_optimizer(m, V33Config())
+    assert [len(g["params"]) for g in opt.param_groups] == [136, 1]
+    assert opt.param_groups[1]["weight_decay"] == 0.0 and opt.param_groups[0]["weight_decay"] == 0.01
+    assert m.vocab_size == 50000 and m.hidden_size == 768
+
+
+def test_hf_export_roundtrip(tmp_path):
+    from src.model.splade_modern import SPLADEModernBERT
+    g = dict(vocab_size=300, hidden_size=256, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+             pad_token_id=299)
+    m = SPLADEModernBERT(config=g)
+    m.model.save_pretrained(str(tmp_path))
+    cfg = json.load(open(tmp_path / "config.json"))
+    assert cfg["model_type"] == "modernbert" and cfg["vocab_size"] == 300
+    m2 = SPLADEModernBERT(model_name=str(tmp_path))
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+
+
+def test_lambda_and_lr_schedules_match_oracle():
+    from oracle import splade_oracle as O
+    from src.model.losses import SPLADELossV33
+    from src.train.core.ddp_trainer import cosine_with_warmup_lambda
+    lf = SPLADELossV33(lambda_q=0.01, lambda_d=0.003, flops_warmup_steps=200, lambda_initial_ratio=0.1)
+    assert lf.lambda_neg == 0.003                                      # falls back to lambda_d
+    for step in (0, 1, 57, 100, 199, 200, 5000):
+        assert lf._lambda_schedule(step, 0.01) == O.lambda_schedule(step, 0.01, 200, 0.1)
+    for s in range(0, 120, 7):
+        assert cosine_with_warmup_lambda(s, 10, 100) == O.cosine_lr_factor(s, 10, 100)
+    assert SPLADELossV33(lambda_neg=0.02).lambda_neg == 0.02
+
+
+def test_config_yaml_sections_and_cli_overrides(tmp_path):
+    import argparse
+    import yaml
+    from src.train.cli.train_v33_ddp import load_config
+    from src.train.config.v33 import V33Config
+    c = V33Config()
+    assert (c.data.batch_size, c.data.query_max_length, c.data.doc_max_length) == (64, 64, 256)
+    assert (c.training.gradient_accumulation_steps, c.training.learning_rate, c.loss.flops_warmup_steps) == (4, 5e-5, 20000)
+    p = tmp_path / "cfg.yaml"
+    p.write_text(yaml.safe_dump({"loss": {"lambda_q": 0.02, "lambda_margin_mse": 0.5}, "data": {"batch_size": 16},
+                                 "training": {"num_epochs": 3}}))
+    ns = argparse.Namespace(config=str(p), epochs=None, batch_size=8, lr=1e-4, output_dir=None, lambda_q=None,
+                            lambda_d=0.001, grad_accum=2, seed=7)
+    cfg = load_config(ns)
+    assert cfg.loss.lambda_q == 0.02 and cfg.loss.lambda_margin_mse == 0.5 and cfg.loss.lambda_d == 0.001
+    assert cfg.data.batch_size == 8 and cfg.training.num_epochs == 3 and cfg.training.learning_rate == 1e-4
+    assert cfg.training.gradient_accumulation_steps == 2 and cfg.training.seed == 7
+    assert V33Config(loss={"lambda_q": 1.0}).loss.lambda_q == 1.0      # dict sections are promoted
+
+
+def test_jsonl_dataset_tokenizer_and_collator(tmp_path):
+    from src.train.data import SyntheticTripletDataset, TripletCollator, load_training_data
+    from src.train.data.collator import HashTokenizer, create_tokenizer
+    f1, f2 = tmp_path / "train_0.jsonl", tmp_path / "train_1.jsonl"
+    f1.write_text(json.dumps({"query": "a b", "positive": "c d e", "negative": "f"}) + "\n\n" +
+                  json.dumps({"query": "g", "positive": "h i", "negative": None}) + "\n")
+    f2.write_text(json.dumps({"query": "j k l", "positive": "m", "negative": "n o"}) + "\n")
+    ds = load_training_data([str(tmp_path / "train_*.jsonl")])
+    assert len(ds) == 3 and ds[2]["query"] == "j k l" and ds[1]["negative"] is None
+    with pytest.raises(FileNotFoundError):
+        load_training_data([str(tmp_path / "nope_*.jsonl")])
+    tok = create_tokenizer("hash:1000")
+    assert isinstance(tok, HashTokenizer) and tok.pad_token_id == 999
+    with pytest.raises(FileNotFoundError):
+        create_tokenizer("skt/A.X-Encoder-base")
+    col = TripletCollator(tok, query_max_length=4, doc_max_length=6)
+    out = col([ds[0], ds[1], ds[2]])
+    assert out["query_input_ids"].shape == (3, 4) and out["num_negatives"] == 1
+    assert out["negative_input_ids"][1].tolist() == out["positive_input_ids"][1].tolist()[:out["negative_input_ids"].shape[1]]
+    assert int(out["query_attention_mask"][1].sum()) == 3                     # <s> g </s>
+    syn = load_training_data(["synthetic:10:3"])
+    assert isinstance(syn, SyntheticTripletDataset) and len(syn[4]["negatives"]) == 3 and syn[4] == syn[4]
+    tok.save_pretrained(str(tmp_path / "tok"))
+    assert create_tokenizer(str(tmp_path / "tok")).vocab_size == 1000
+
+
+def test_checkpoint_layout_and_resume(tmp_path):
+    """checkpoint_epoch{E}_step{S}/{model.pt, training_state.pt, config.json} (ref:train_v33_ddp.py:192-286)."""
+    from src.model.splade_modern import SPLADEModernBERT
+    from src.train.config.v33 import V33Config
+    from src.train.core import ddp_trainer as T
+    g = dict(vocab_size=300, hidden_size=256, intermediate_size=128, num_hidden_layers=1, num_attention_heads=4,
+             pad_token_id=299)
+    m = SPLADEModernBERT(config=g)
+    cfg = V33Config()
+    opt = T.build_optimizer(m, cfg)
+    sch = T.build_scheduler(opt, 2, 10)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p) * 1e-3
+    opt.step(); sch.step()
+    path = T.save_checkpoint(m, opt, sch, epoch=2, global_step=30, output_dir=str(tmp_path), config=cfg, best_metric=0.5)
+    T.save_checkpoint(m, opt, sch, epoch=1, global_step=7, output_dir=str(tmp_path), config=cfg)
+    assert sorted(os.listdir(path)) == ["config.json", "model.pt", "training_state.pt"]
+    assert T.find_latest_checkpoint(str(tmp_path)).endswith("checkpoint_epoch2_step30")
+    assert T.find_latest_checkpoint(str(tmp_path / "missing")) is None
+    m2 = SPLADEModernBERT(config=g)
+    opt2 = T.build_optimizer(m2, cfg)
+    sch2 = T.build_scheduler(opt2, 2, 10)
+    st = T.load_checkpoint(m2, opt2, sch2, path)
+    assert (st["epoch"], st["global_step"], st["best_metric"]) == (2, 30, 0.5)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    assert sch2.last_epoch == 1
+    os.remove(os.path.join(path, "training_state.pt"))
+    assert T.load_checkpoint(m2, None, None, path) == {"epoch": -1, "global_step": 0}
+
+
+def test_tensorboard_logger_does_not_need_tensorboard(tmp_path):
+    from src.train.utils import TensorBoardLogger, setup_logging
+    tb = TensorBoardLogger(log_dir=str(tmp_path), experiment_name="x")
+    tb.log_scalar("train/loss", torch.tensor(1.5), 3)
+    tb.close()
+    setup_logging(output_dir=str(tmp_path), log_file="t.log").info("hello")
+    assert (tmp_path / "t.log").exists()
+
+
+def test_get_top_k_tokens_tie_order():
+    from src.model.splade_modern import SPLADEModernBERT
+    g = dict(vocab_size=300, hidden_size=256, intermediate_size=128, num_hidden_layers=1, num_attention_heads=4,
+             pad_token_id=299)
+    m = SPLADEModernBERT(config=g)
+
+    class Tok:
+        def decode(self, ids):
+            return f" t{ids[0]} "
+    v = torch.zeros(300)
+    v[[5, 17, 200]] = torch.tensor([2.0, 3.0, 2.0])
+    out = m.get_top_k_tokens(v, Tok(), k=10)
+    assert list(out.items()) == [("t17", 3.0), ("t5", 2.0), ("t200", 2.0)]     # tie: lowest index first, zeros dropped
+
+
+# ---------------------------------------------------------------------------------- multi-process (gloo)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dist_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import splade_oracle as O
+    from snx import dist as sd
+    torch.manual_seed(0)
+    # (1) flat-gradient all-reduce == DDP's mean over ranks
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    sd.allreduce_flat_grads(flat)
+    ok1 = torch.allclose(flat, torch.arange(10, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
+    # (2) all-gather with reduce-scatter backward: cross-rank in-batch negatives identity (config 4)
+    g = torch.Generator().manual_seed(123)
+    B, V = 3, 40
+    A = [torch.rand(B, V, generator=g) for _ in range(world)]
+    P = [torch.rand(B, V, generator=g) for _ in range(world)]
+    N = [torch.rand(B, V, generator=g) for _ in range(world)]
+    a, p, n = (t[rank].clone().requires_grad_(True) for t in (A, P, N))
+    pall = sd.all_gather_with_grad(p)
+    loss = O.cross_rank_infonce(a, pall, n, rank, 1.5)
+    loss.backward()
+    # single-process reference: sum over ranks of each rank's loss, differentiate w.r.t. every P
+    Ps = [t.clone().requires_grad_(True) for t in P]
+    tot = 0
+    for r in range(world):
+        tot = tot + O.cross_rank_infonce(A[r], torch.cat(Ps, 0), N[r], r, 1.5)
+    tot.backward()
+    ok2 = torch.allclose(p.grad, Ps[rank].grad, atol=1e-6) and pall.shape == (world * B, V)
+    from src.train.core import ddp_trainer as T
+    ok3 = T.is_main_process() == (rank == 0)
+    ret[rank] = (bool(ok1), bool(ok2), bool(ok3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_collectives_gloo():
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dist_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: (True, True, True), 1: (True, True, True)}
