@@ -7,7 +7,7 @@
 
 enum { EPI_STORE_BF16 = 0, EPI_RESID_F32 = 1 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int STAGES>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N, int K, int tiles_n, int ntiles,
     bf16_t* __restrict__ Cb, const float* __restrict__ Hin, float* __restrict__ Hout) {
@@ -20,7 +20,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
   for (int i = 0; i < Core::MI; ++i)
 #pragma unroll
     for (int j = 0; j < Core::NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
+  if (STAGES == 3) Core::template mainloop3<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
+  else Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
   // transposed accumulators: this lane owns columns col..col+3 of row `row` (8-B / 16-B accesses)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -44,19 +45,37 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
   }
 }
 
+static int g_nt_variant = -1;     // -1: auto; 0: 128x128 2-stage; 1: 128x128 3-stage; 2: 256x128 3-stage (tuning knob)
+extern "C" int snx_debug_set_gemm_variant(int32_t v) { g_nt_variant = v; return SNX_OK; }
+
+template <int BM, int BN, int WM, int WN, int EPI, int STAGES>
+static int launch_nt_cfg(const void* A, const void* B, int M, int N, int K, void* Cb, const float* Hin, float* Hout,
+                         hipStream_t st) {
+  using Core = GemmCore<BM, BN, WM, WN>;
+  const int tm = cdiv(M, BM), tn = cdiv(N, BN);
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, EPI, STAGES>;
+  const int lds = STAGES == 3 ? Core::LDS_BYTES3 : Core::LDS_BYTES;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(Core::NTHREADS), lds, st, (const bf16_t*)A, (const bf16_t*)B, M, N, K,
+                     tn, tm * tn, (bf16_t*)Cb, Hin, Hout);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
 template <int EPI>
 static int launch_nt(const void* A, const void* B, int M, int N, int K, void* Cb, const float* Hin, float* Hout,
                      hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0) return SNX_E_SHAPE;
   if (!A || !B) return SNX_E_ARG;
-  constexpr int BM = 128, BN = 128;
-  using Core = GemmCore<BM, BN, 2, 2>;
-  const int tm = cdiv(M, BM), tn = cdiv(N, BN);
-  auto kern = gemm_nt_kernel<BM, BN, 2, 2, EPI>;
-  hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(Core::NTHREADS), Core::LDS_BYTES, st, (const bf16_t*)A,
-                     (const bf16_t*)B, M, N, K, tn, tm * tn, (bf16_t*)Cb, Hin, Hout);
-  SNX_CHECK_LAUNCH();
-  return SNX_OK;
+  int v = g_nt_variant;
+  if (v < 0) v = 0;
+  if (v == 2) return launch_nt_cfg<256, 128, 4, 2, EPI, 3>(A, B, M, N, K, Cb, Hin, Hout, st);
+  if (v == 1) return launch_nt_cfg<128, 128, 2, 2, EPI, 3>(A, B, M, N, K, Cb, Hin, Hout, st);
+  return launch_nt_cfg<128, 128, 2, 2, EPI, 2>(A, B, M, N, K, Cb, Hin, Hout, st);
 }
 
 extern "C" int snx_gemm_nt_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K,

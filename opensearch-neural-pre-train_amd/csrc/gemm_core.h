@@ -11,6 +11,12 @@
 // to the per-lane SOURCE address and again on the read (same involution).
 #pragma once
 #include "common.h"
+#ifndef SNX_GEMM_SETPRIO
+#define SNX_GEMM_SETPRIO 0
+#endif
+#ifndef SNX_GEMM_SCHED
+#define SNX_GEMM_SCHED 1
+#endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 struct GemmCore {
@@ -53,8 +59,8 @@ struct GemmCore {
                                                       f32x4 (&acc)[MI][NI]) {
     const char* ta = cur;
     const char* tb = cur + A_BYTES;
-    // all 2*(MI+NI) fragment reads are issued up front: the k=32..63 reads are still in flight
-    // while the k=0..31 MFMAs run (the compiler's counted lgkmcnt waits do the rest)
+    // all 2*(MI+NI) fragment reads are issued up front; the scheduler is then told to interleave
+    // them with the MFMAs (1 MFMA : 1 DS read) so the k=32..63 reads fly under the k=0..31 MFMAs
     bf16x8 a[2][MI], b[2][NI];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -64,6 +70,9 @@ struct GemmCore {
 #pragma unroll
       for (int j = 0; j < NI; ++j) b[kk][j] = frag(tb, wn * WTN + j * 16 + (lane & 15), chunk);
     }
+#if SNX_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -72,6 +81,21 @@ struct GemmCore {
         for (int j = 0; j < NI; ++j)
           acc[i][j] = TRANSPOSED ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0)
                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+#if SNX_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#if SNX_GEMM_SCHED
+    // first (MI+NI) reads must land before the first MFMA; afterwards pair each of the remaining
+    // (MI+NI) reads with an MFMA
+#pragma unroll
+    for (int q = 0; q < MI + NI; ++q) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int q = 0; q < MI + NI; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * MI * NI - (MI + NI), 0);
+#endif
   }
 
   // acc must be zero-initialised (or hold the running sum) by the caller.
@@ -98,6 +122,49 @@ struct GemmCore {
         stage<BN>(B, ldb, n0, N, (kt + 1) * BK, nxt + A_BYTES, wave, lane);
       }
       compute_step<TRANSPOSED>(cur, wm, wn, lane, acc);
+    }
+  }
+
+  // Three-stage variant: K-tiles kt+1 and kt+2 are in flight while tile kt is multiplied.  The
+  // wait is a COUNTED vmcnt (the newest tile's DMA stays in flight across the barrier) and the
+  // barrier is a raw s_barrier (__syncthreads() would drain vmcnt to 0).  One barrier per K-step:
+  // after it every wave has (a) seen tile kt land and (b) finished reading tile kt-1, whose buffer
+  // is the one tile kt+2 is staged into.
+  static constexpr int LDS_BYTES3 = 3 * STAGE_BYTES;
+  static constexpr int DMA_PER_STAGE = BM / 8 / NW + BN / 8 / NW;   // LDS-DMA instructions per wave per K-tile
+  template <bool TRANSPOSED = false>
+  static __device__ __forceinline__ void mainloop3(const bf16_t* __restrict__ A, long lda, int m0, int M,
+                                                   const bf16_t* __restrict__ B, long ldb, int n0, int N,
+                                                   int K, char* smem, f32x4 (&acc)[MI][NI]) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int nk = K / BK;
+    stage<BM>(A, lda, m0, M, 0, smem, wave, lane);
+    stage<BN>(B, ldb, n0, N, 0, smem + A_BYTES, wave, lane);
+    if (nk > 1) {
+      stage<BM>(A, lda, m0, M, BK, smem + STAGE_BYTES, wave, lane);
+      stage<BN>(B, ldb, n0, N, BK, smem + STAGE_BYTES + A_BYTES, wave, lane);
+    }
+    int cur = 0;                                      // buffer index of tile kt (kt % 3)
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        static_assert(DMA_PER_STAGE == 4 || DMA_PER_STAGE == 6 || DMA_PER_STAGE == 8, "add a vmcnt case");
+        if (DMA_PER_STAGE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (DMA_PER_STAGE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (DMA_PER_STAGE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) {
+        const int nb = cur == 0 ? 2 : cur - 1;        // (kt + 2) % 3
+        char* nxt = smem + nb * STAGE_BYTES;
+        stage<BM>(A, lda, m0, M, (kt + 2) * BK, nxt, wave, lane);
+        stage<BN>(B, ldb, n0, N, (kt + 2) * BK, nxt + A_BYTES, wave, lane);
+      }
+      compute_step<TRANSPOSED>(smem + cur * STAGE_BYTES, wm, wn, lane, acc);
+      cur = cur == 2 ? 0 : cur + 1;
     }
   }
 

@@ -54,8 +54,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer([s] + headers, o):
-            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-I", INCLUDE, "-I", CSRC,
-                         "-c", s, "-o", o])
+            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-I", INCLUDE, "-I", CSRC]
+                        + os.environ.get("SNX_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
