@@ -80,8 +80,11 @@ size_t snx_model_keys_offset(const snx_model_desc* d, int32_t T, int32_t nseq);
 int snx_model_forward(const snx_model_desc* d, const void* const* params /*[host]*/, const void* wcache,
                       const int64_t* ids, const int64_t* mask, const int32_t* cu_seqlens, const int32_t* pos,
                       const float* rope_global, const float* rope_local, void* saved, float* sparse,
-                      float* token_weights, void* reserved, int32_t T, int32_t nseq, int32_t max_seqlen,
-                      int32_t flags, hipStream_t stream);
+                      float* token_weights, const int32_t* groups /*[host] or NULL*/, int32_t T, int32_t nseq,
+                      int32_t max_seqlen, int32_t flags, hipStream_t stream);
+/* `groups` (optional): {n, (seq_begin, nseq, max_len) x n} -- consecutive sequence groups of different
+ * maximum length laid end to end in ONE call (e.g. the query, positive and negative batches of a
+ * training micro-step); NULL = one group of nseq sequences. */
 
 /* Backward of the above (the autograd graph of ref:src/model/splade_modern.py:69-86 and of the HF
  * encoder): g_sparse [nseq, vocab] fp32 = dL/d sparse_repr; every grads[i] (fp32, same shape as
@@ -157,6 +160,10 @@ int snx_attn_bwd(const void* qkv, const void* out, const void* dout, const float
 
 /* Tied decoder GEMM + SPLADE tail fused (hf:550 + ref:src/model/splade_modern.py:76-86). */
 size_t snx_splade_head_scratch_bytes(int32_t T, int32_t V);
+int snx_decoder_splade_fwd_ex(const void* Hd, const void* W, const float* bias, const int32_t* cu_seqlens,
+                              const int64_t* mask, float* sparse, uint32_t* keys, float* token_weights, void* scratch,
+                              int32_t T, int32_t nseq, int32_t max_seqlen, int32_t V, int32_t K, int32_t finalize,
+                              hipStream_t stream);
 int snx_decoder_splade_fwd(const void* Hd, const void* W, const float* bias, const int32_t* cu_seqlens,
                            const int64_t* mask, float* sparse, uint32_t* keys, float* token_weights, void* scratch,
                            int32_t T, int32_t nseq, int32_t max_seqlen, int32_t V, int32_t K, hipStream_t stream);

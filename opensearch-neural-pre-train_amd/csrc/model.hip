@@ -239,9 +239,8 @@ extern "C" size_t snx_model_bwd_workspace_bytes(const snx_model_desc* d, int32_t
 extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* params, const void* wcache,
                                  const int64_t* ids, const int64_t* mask, const int32_t* cu_seqlens,
                                  const int32_t* pos, const float* rope_global, const float* rope_local, void* saved,
-                                 float* sparse, float* token_weights, void* reserved, int32_t T, int32_t nseq,
-                                 int32_t max_seqlen, int32_t flags, hipStream_t st) {
-  (void)reserved;
+                                 float* sparse, float* token_weights, const int32_t* groups, int32_t T,
+                                 int32_t nseq, int32_t max_seqlen, int32_t flags, hipStream_t st) {
   if (!desc_ok(d)) return SNX_E_SHAPE;
   if (!params || !wcache || !ids || !mask || !cu_seqlens || !pos || !rope_global || !rope_local || !saved || !sparse ||
       !token_weights || T <= 0 || nseq <= 0 || max_seqlen <= 0)
@@ -276,9 +275,20 @@ extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* par
   { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * L), F(p.final_norm()), sv + s.xf, T, H, d->ln_eps, st)); }
   { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(sv + s.xf, wc + c.dense, sv + s.dd, T, H, H, st)); }
   { PROF(PC_LN_FWD, TH * 4); RC(snx_gelu_ln_fwd(sv + s.dd, F(p.head_norm()), sv + s.hd, T, H, d->ln_eps, st)); }
-  { PROF(PC_DECODER_SPLADE, 2.0 * TH * V);
-    RC(snx_decoder_splade_fwd(sv + s.hd, wc + c.emb, F(p.dec_bias()), cu_seqlens, mask, sparse,
-                              (uint32_t*)(sv + s.keys), token_weights, sv + s.rowpart, T, nseq, max_seqlen, V, H, st)); }
+  {
+    // Sequence groups (e.g. 64-token queries and 256-token documents concatenated in one call)
+    // get the decoder tile height that fits their length; groups = {n, (seq_begin, nseq, max_len)*n}.
+    PROF(PC_DECODER_SPLADE, 2.0 * TH * V);
+    int32_t one[4] = {1, 0, nseq, max_seqlen};
+    const int32_t* g = groups ? groups : one;
+    for (int i = 0; i < g[0]; ++i) {
+      const int sb = g[1 + 3 * i], ns = g[2 + 3 * i], ml = g[3 + 3 * i];
+      if (sb < 0 || ns <= 0 || sb + ns > nseq || ml <= 0 || ml > max_seqlen) return SNX_E_ARG;
+      RC(snx_decoder_splade_fwd_ex(sv + s.hd, wc + c.emb, F(p.dec_bias()), cu_seqlens + sb, mask,
+                                   sparse + (size_t)sb * V, (uint32_t*)(sv + s.keys) + (size_t)sb * V, token_weights,
+                                   sv + s.rowpart, T, ns, ml, V, H, i + 1 == g[0], st));
+    }
+  }
   return SNX_OK;
 }
 

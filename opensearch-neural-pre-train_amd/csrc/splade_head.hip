@@ -122,10 +122,13 @@ __global__ void token_weights_kernel(const unsigned short* __restrict__ rowpart,
 
 extern "C" size_t snx_splade_head_scratch_bytes(int32_t T, int32_t V) { return (size_t)cdiv(V, 128) * T * 2; }
 
-extern "C" int snx_decoder_splade_fwd(const void* Hd, const void* W, const float* bias, const int32_t* cu_seqlens,
-                                      const int64_t* mask, float* sparse, uint32_t* keys, float* token_weights,
-                                      void* scratch, int32_t T, int32_t nseq, int32_t max_seqlen, int32_t V,
-                                      int32_t K, hipStream_t st) {
+// `finalize` = 0 skips the token_weights pass (used when several sequence groups of one token
+// buffer are processed by separate calls; the last call finalises all T rows).
+extern "C" int snx_decoder_splade_fwd_ex(const void* Hd, const void* W, const float* bias,
+                                         const int32_t* cu_seqlens, const int64_t* mask, float* sparse,
+                                         uint32_t* keys, float* token_weights, void* scratch, int32_t T,
+                                         int32_t nseq, int32_t max_seqlen, int32_t V, int32_t K, int32_t finalize,
+                                         hipStream_t st) {
   if (!Hd || !W || !bias || !cu_seqlens || !mask || !sparse || !keys || !token_weights || !scratch) return SNX_E_ARG;
   if (T <= 0 || nseq <= 0 || V <= 0 || K <= 0 || (K % 64) || max_seqlen > 65535) return SNX_E_SHAPE;
   const int n_tiles = cdiv(V, 128);
@@ -143,10 +146,20 @@ extern "C" int snx_decoder_splade_fwd(const void* Hd, const void* W, const float
                        (const bf16_t*)W, bias, cu_seqlens, mask, sparse, keys, rowpart, T, V, K, n_tiles, total);
   }
   SNX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(token_weights_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, rowpart, mask, token_weights, T,
-                     n_tiles);
-  SNX_CHECK_LAUNCH();
+  if (finalize) {
+    hipLaunchKernelGGL(token_weights_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, rowpart, mask, token_weights, T,
+                       n_tiles);
+    SNX_CHECK_LAUNCH();
+  }
   return SNX_OK;
+}
+
+extern "C" int snx_decoder_splade_fwd(const void* Hd, const void* W, const float* bias, const int32_t* cu_seqlens,
+                                      const int64_t* mask, float* sparse, uint32_t* keys, float* token_weights,
+                                      void* scratch, int32_t T, int32_t nseq, int32_t max_seqlen, int32_t V,
+                                      int32_t K, hipStream_t st) {
+  return snx_decoder_splade_fwd_ex(Hd, W, bias, cu_seqlens, mask, sparse, keys, token_weights, scratch, T, nseq,
+                                   max_seqlen, V, K, 1, st);
 }
 
 // ==========================================================================================

@@ -38,6 +38,7 @@ SIGNATURES = {
     "snx_attn_bwd": (I32, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_splade_head_scratch_bytes": (SZ, [I32, I32]),
     "snx_decoder_splade_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),
+    "snx_decoder_splade_fwd_ex": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_splade_bwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),
     "snx_loss_workspace_bytes": (SZ, [I32, I32, I32, I32]),
     "snx_loss_fwd": (I32, [P, P, P, P, P, P, P, P, P, P]),

@@ -116,14 +116,6 @@ class EncoderRuntime:
                              rope_table(max_pos, 64, self.geom.local_rope_theta, dev))
         return self._rope[k]
 
-    def _seq_layout(self, B: int, S: int, dev):
-        k = (B, S, str(dev))
-        if k not in self._seq_cache:
-            cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
-            pos = torch.arange(S, dtype=torch.int32).repeat(B).to(dev)
-            self._seq_cache[k] = (cu, pos)
-        return self._seq_cache[k]
-
     # ------------------------------------------------------------------ gradients
     def enable_direct_grads(self, on: bool = True):
         """Accumulate parameter gradients straight into one flat fp32 buffer whose slices ARE the
@@ -149,28 +141,55 @@ class EncoderRuntime:
 
     # ------------------------------------------------------------------ forward / backward
     def forward_impl(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool):
+        return self.forward_many_impl([(input_ids, attention_mask)], save)
+
+    def forward_many_impl(self, pairs, save: bool):
+        """One native forward over several [B_i, S_i] batches laid end to end (sequence groups).
+        -> sparse [sum B_i, V], token_weights [sum B_i*S_i] (flat), arena, aux."""
         dev = self._device()
-        if input_ids.dim() != 2 or attention_mask.shape != input_ids.shape:
-            raise ValueError("input_ids and attention_mask must both be [batch, seq_len]")
-        if input_ids.device != dev or attention_mask.device != dev:
-            raise ValueError("inputs must live on the module's device")
-        B, S = input_ids.shape
-        if S > self.geom.max_position_embeddings or S > 65535:
-            raise ValueError("sequence too long")
-        ids = input_ids.to(torch.int64).contiguous().view(-1)
-        mask = attention_mask.to(torch.int64).contiguous().view(-1)
-        T = B * S
-        cu, pos = self._seq_layout(B, S, dev)
-        rg, rl = self._rope_tables(max(S, 64), dev)
+        shapes = []
+        for ids, mask in pairs:
+            if ids.dim() != 2 or mask.shape != ids.shape:
+                raise ValueError("input_ids and attention_mask must both be [batch, seq_len]")
+            if ids.device != dev or mask.device != dev:
+                raise ValueError("inputs must live on the module's device")
+            if ids.shape[1] > self.geom.max_position_embeddings or ids.shape[1] > 8192:
+                raise ValueError("sequence too long")
+            shapes.append((int(ids.shape[0]), int(ids.shape[1])))
+        if len(pairs) == 1:
+            ids = pairs[0][0].to(torch.int64).contiguous().view(-1)
+            mask = pairs[0][1].to(torch.int64).contiguous().view(-1)
+        else:
+            ids = torch.cat([p[0].to(torch.int64).reshape(-1) for p in pairs])
+            mask = torch.cat([p[1].to(torch.int64).reshape(-1) for p in pairs])
+        key = (tuple(shapes), str(dev))
+        lay = self._seq_cache.get(key)
+        if lay is None:
+            cu, pos, groups, t0, s0 = [0], [], [len(shapes)], 0, 0
+            for B, S in shapes:
+                cu += [t0 + (b + 1) * S for b in range(B)]
+                pos.append(torch.arange(S, dtype=torch.int32).repeat(B))
+                groups += [s0, B, S]
+                t0 += B * S
+                s0 += B
+            lay = (torch.tensor(cu, dtype=torch.int32).to(dev), torch.cat(pos).to(dev),
+                   (C.c_int32 * len(groups))(*groups))
+            self._seq_cache[key] = lay
+        cu, pos, groups = lay
+        T = sum(B * S for B, S in shapes)
+        nseq = sum(B for B, _ in shapes)
+        smax = max(S for _, S in shapes)
+        rg, rl = self._rope_tables(max(smax, 64), dev)
         wc = self._weights()
-        nbytes = fn("snx_model_workspace_bytes")(C.byref(self._desc), T, B, int(save))
+        nbytes = fn("snx_model_workspace_bytes")(C.byref(self._desc), T, nseq, int(save))
         saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        sparse = torch.empty((B, self.geom.vocab_size), dtype=torch.float32, device=dev)
-        tw = torch.empty((B, S), dtype=torch.float32, device=dev)
+        sparse = torch.empty((nseq, self.geom.vocab_size), dtype=torch.float32, device=dev)
+        tw = torch.empty((T,), dtype=torch.float32, device=dev)
         check(fn("snx_model_forward")(C.byref(self._desc), self._param_ptrs(), _p(wc), _p(ids), _p(mask), _p(cu),
-                                      _p(pos), _p(rg), _p(rl), _p(saved), _p(sparse), _p(tw), None, T, B, S,
+                                      _p(pos), _p(rg), _p(rl), _p(saved), _p(sparse), _p(tw),
+                                      groups if len(shapes) > 1 else None, T, nseq, smax,
                                       SNX_FWD_SAVE_FOR_BACKWARD if save else 0, _stream()), "snx_model_forward")
-        aux = (ids, mask, cu, pos, rg, rl, T, B, S)
+        aux = (ids, mask, cu, pos, rg, rl, T, nseq, smax)
         return sparse, tw, saved, aux
 
     def routing_rows(self, saved: torch.Tensor, aux) -> torch.Tensor:
@@ -182,7 +201,7 @@ class EncoderRuntime:
         return 0xFFFF - (keys & 0xFFFF)
 
     def backward_impl(self, saved: torch.Tensor, aux, g_sparse: torch.Tensor):
-        ids, mask, cu, pos, rg, rl, T, B, S = aux
+        ids, mask, cu, pos, rg, rl, T, B, S = aux          # B = total sequences, S = longest
         dev = self._device()
         if g_sparse.shape != (B, self.geom.vocab_size):
             raise ValueError("bad gradient shape")
@@ -206,16 +225,32 @@ class EncoderRuntime:
         return ret
 
     def __call__(self, input_ids, attention_mask):
+        (out,) = self.forward_many([(input_ids, attention_mask)])
+        return out
+
+    def forward_many(self, pairs):
+        """[(ids [B_i,S_i], mask)] -> [(sparse_repr [B_i,V], token_weights [B_i,S_i])], one native pass."""
+        pairs = list(pairs)
+        flat = [t for p in pairs for t in p]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.params):
-            return _SpladeEncodeFn.apply(self, input_ids, attention_mask, *self.params)
-        sparse, tw, _, _ = self.forward_impl(input_ids, attention_mask, save=False)
-        return sparse, tw
+            sparse, tw = _SpladeEncodeFn.apply(self, len(pairs), *flat, *self.params)
+        else:
+            sparse, tw, _, _ = self.forward_many_impl(pairs, save=False)
+        out, r0, t0 = [], 0, 0
+        for ids, _ in pairs:
+            B, S = ids.shape
+            out.append((sparse[r0:r0 + B], tw[t0:t0 + B * S].view(B, S)))
+            r0 += B
+            t0 += B * S
+        return out
 
 
 class _SpladeEncodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rt: EncoderRuntime, input_ids, attention_mask, *params):
-        sparse, tw, saved, aux = rt.forward_impl(input_ids, attention_mask, save=True)
+    def forward(ctx, rt: EncoderRuntime, n_pairs: int, *args):
+        pairs = [(args[2 * i], args[2 * i + 1]) for i in range(n_pairs)]
+        ctx.n_in = 2 * n_pairs
+        sparse, tw, saved, aux = rt.forward_many_impl(pairs, save=True)
         ctx.rt, ctx.saved_arena, ctx.aux = rt, saved, aux
         rt.last_ctx = (saved, aux)          # debugging / parity tests: routing of the latest forward
         ctx.mark_non_differentiable(tw)
@@ -226,6 +261,7 @@ class _SpladeEncodeFn(torch.autograd.Function):
         rt = ctx.rt
         grads = rt.backward_impl(ctx.saved_arena, ctx.aux, g_sparse)
         ctx.saved_arena = None
+        head = (None, None) + tuple(None for _ in range(ctx.n_in))
         if grads is None:
-            return (None, None, None) + tuple(None for _ in rt.params)
-        return (None, None, None) + tuple(grads)
+            return head + tuple(None for _ in rt.params)
+        return head + tuple(grads)

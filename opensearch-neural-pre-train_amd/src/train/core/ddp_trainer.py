@@ -181,6 +181,13 @@ def _cross_gpu_negatives(config) -> bool:
         os.environ.get("SNX_CROSS_GPU_NEGATIVES", "0") == "1"
 
 
+def _fuse_passes(model) -> bool:
+    """The three encoder passes of a micro-step run as ONE native pass unless the model is wrapped in
+    torch DDP (whose reducer must see ``DDP.forward``) or SNX_FUSED_PASSES=0."""
+    return (not isinstance(model, DDP)) and hasattr(unwrap(model), "forward_many") and \
+        os.environ.get("SNX_FUSED_PASSES", "1") != "0"
+
+
 def micro_step(model, loss_fn: SPLADELossV33, batch: dict, global_step: int, device: torch.device,
                grad_accum: int, cross_gpu_negatives: bool = False):
     """One micro-batch: three encoder passes, loss, backward (ref:train_v33_ddp.py:321-364)."""
@@ -198,9 +205,13 @@ def micro_step(model, loss_fn: SPLADELossV33, batch: dict, global_step: int, dev
     if t_neg is not None:
         t_neg = t_neg.to(device)
     with autocast(device_type=device.type, dtype=torch.bfloat16, enabled=nb):
-        anchor_repr, _ = model(q_ids, q_mask)
-        positive_repr, _ = model(p_ids, p_mask)
-        negative_repr, _ = model(n_ids, n_mask)
+        if _fuse_passes(model):
+            (anchor_repr, _), (positive_repr, _), (negative_repr, _) = unwrap(model).forward_many(
+                [(q_ids, q_mask), (p_ids, p_mask), (n_ids, n_mask)])
+        else:
+            anchor_repr, _ = model(q_ids, q_mask)
+            positive_repr, _ = model(p_ids, p_mask)
+            negative_repr, _ = model(n_ids, n_mask)
         if num_negatives > 1:
             negative_repr = negative_repr.view(anchor_repr.shape[0], num_negatives, -1)
         extra = {}

@@ -321,3 +321,24 @@ def test_inference_matches_training_forward(dev, full_setup):
     b, _ = model(ids.to(dev), mask.to(dev))
     assert torch.equal(a, b.detach())
     assert torch.equal(model.encode(ids.to(dev), mask.to(dev)).detach(), a)
+
+
+def test_forward_many_equals_separate_passes(dev):
+    """q/p/n batches in ONE native pass (sequence groups) give the same outputs and gradients."""
+    from oracle import splade_oracle as O
+    cfg = _small_cfg()
+    params = O.perturb_params(O.init_params(cfg, seed=3), seed=4, scale=2.0, bias_mean=-0.1)
+    gen = torch.Generator().manual_seed(55)
+    b = O.synth_batch(5, 40, 150, cfg, gen, k=2, ragged=True)
+    pairs = [(b[t + "_input_ids"].to(dev), b[t + "_attention_mask"].to(dev)) for t in ("query", "positive", "negative")]
+    m1, m2 = _build_model(cfg, params, dev), _build_model(cfg, params, dev)
+    sep = [m1(i, m) for i, m in pairs]
+    many = m2.forward_many(pairs)
+    w = [torch.randn_like(s[0]) for s in sep]
+    sum((s[0] * wi).sum() for s, wi in zip(sep, w)).backward()
+    sum((s[0] * wi).sum() for s, wi in zip(many, w)).backward()
+    for (s1, t1), (s2, t2) in zip(sep, many):
+        assert torch.equal(s1, s2) and torch.equal(t1, t2)
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        cos, rel = _grad_stats(p2.grad, p1.grad)
+        assert cos > 0.99999 and rel < 2e-3, (n1, cos, rel)      # fp32 atomics order only
