@@ -18,9 +18,47 @@
 #include "snx.h"
 
 #define NEG_BIG (-1.0e30f)
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
 
+// 2^x on the transcendental unit (v_exp_f32); softmax runs in the log2 domain so that each
+// probability costs one FMA + one v_exp.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// true when every (query, key) pair of a 16-query x 64-key (or 64-query x 16-key) block lies inside
+// the band |q - k| <= window, so the per-element band test can be skipped (wave-uniform).
+__device__ __forceinline__ bool band_clean(int window, int a_lo, int a_hi, int b_lo, int b_hi) {
+  return window < 0 || (a_hi - b_lo <= window && b_hi - a_lo <= window);
+}
+
+// Register-staged tile (async-STAGE split): the global loads of tile t+1 are issued right after
+// tile t has been written to LDS and stay in flight while tile t is multiplied; they are written
+// to LDS after the next barrier.  Each thread carries 2 x 16 B of the 64x64 bf16 tile.
+struct TileRegs { bf16x8 v[2]; };
+__device__ __forceinline__ void tile_load(TileRegs& t, const bf16_t* __restrict__ base, long row_stride, int r0g,
+                                          int rmax) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = threadIdx.x + i * 256;
+    const int r = id >> 3, c = id & 7;
+    int gr = r0g + r;
+    gr = gr < rmax ? gr : rmax - 1;
+    t.v[i] = *(const bf16x8*)(base + (long)gr * row_stride + c * 8);
+  }
+}
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
+
+// write to a row image (k_off swizzle, ds_read_b128 rows) and/or a transposed-read image (v_off)
+__device__ __forceinline__ void tile_store(const TileRegs& t, char* lds_row, char* lds_tr) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = threadIdx.x + i * 256;
+    const int r = id >> 3, c = id & 7;
+    if (lds_row) *(bf16x8*)(lds_row + k_off(r, c)) = t.v[i];
+    if (lds_tr) *(bf16x8*)(lds_tr + v_off(r, c)) = t.v[i];
+  }
+}
 
 __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
@@ -49,6 +87,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   __shared__ __attribute__((aligned(16))) char sK[64 * 128];
   __shared__ __attribute__((aligned(16))) char sV[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sValid[64];
+  __shared__ int sAllValid;
   const int seq = blockIdx.z, head = blockIdx.y;
   const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
   const int q0 = blockIdx.x * 64;
@@ -80,14 +119,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_run = NEG_BIG, l_run = 0.f;
 
+  TileRegs rk, rv;
+  tile_load(rk, kbase, rs, j_lo * 64, slen);
+  tile_load(rv, vbase, rs, j_lo * 64, slen);
   for (int j = j_lo; j <= j_hi; ++j) {
     const int key0 = j * 64;
     __syncthreads();                                 // previous tile fully consumed
-    stage_kv<false>(kbase, rs, key0, slen, sK);
-    stage_kv<true>(vbase, rs, key0, slen, sV);
+    tile_store(rk, sK, nullptr);
+    tile_store(rv, nullptr, sV);
+    if (j < j_hi) {                                  // next tile's loads fly under this tile's math
+      tile_load(rk, kbase, rs, key0 + 64, slen);
+      tile_load(rv, vbase, rs, key0 + 64, slen);
+    }
     if (threadIdx.x < 64) {
       const int key = key0 + threadIdx.x;
-      sValid[threadIdx.x] = (key < slen && mask[s0 + key] != 0) ? 1 : 0;
+      const bool v = key < slen && mask[s0 + key] != 0;
+      sValid[threadIdx.x] = v ? 1 : 0;
+      const unsigned long long all = __ballot(v);
+      if (threadIdx.x == 0) sAllValid = (all == ~0ull) ? 1 : 0;
     }
     __syncthreads();
 
@@ -102,34 +151,47 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[c], s[kt], 0, 0, 0);
       }
     }
+    // scores in the log2 domain: t = s * (scale * log2 e); masked entries -> NEG_BIG
+    const float c2 = scale * LOG2E;
+    const bool clean = sAllValid && band_clean(window, q0 + wave * 16, q0 + wave * 16 + 15, key0, key0 + 63);
     float mx = NEG_BIG;
+    if (clean) {
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const uint32_t vm = *(const uint32_t*)(sValid + kt * 16 + g * 4);
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + kt * 16 + g * 4 + r;
-        bool ok = (vm >> (8 * r)) & 1;
-        if (window >= 0) {
-          const int dlt = qpos - key;
-          ok = ok && (dlt <= window) && (dlt >= -window);
+        for (int r = 0; r < 4; ++r) {
+          s[kt][r] *= c2;
+          mx = fmaxf(mx, s[kt][r]);
         }
-        const float v = ok ? s[kt][r] * scale : NEG_BIG;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const uint32_t vm = *(const uint32_t*)(sValid + kt * 16 + g * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + kt * 16 + g * 4 + r;
+          bool ok = (vm >> (8 * r)) & 1;
+          if (window >= 0) {
+            const int dlt = qpos - key;
+            ok = ok && (dlt <= window) && (dlt >= -window);
+          }
+          const float v = ok ? s[kt][r] * c2 : NEG_BIG;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = fast_exp2(m_run - m_new);
     float rsum = 0.f;
     bf16x8 pb[2];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __expf(s[kt][r] - m_new);
+        const float p = fast_exp2(s[kt][r] - m_new);
         rsum += p;
         pb[kt >> 1][(kt & 1) * 4 + r] = f2bf(p);
       }
@@ -164,7 +226,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       bf16x4 v = {f2bf(o[d][0] * inv), f2bf(o[d][1] * inv), f2bf(o[d][2] * inv), f2bf(o[d][3] * inv)};
       *(bf16x4*)(orow + d * 16) = v;
     }
-    if (g == 0) lse[(long)head * T + s0 + qpos] = m_run + __logf(l_run);
+    if (g == 0) lse[(long)head * T + s0 + qpos] = (m_run + __log2f(l_run)) * LN2;   // natural-log LSE
   }
 }
 
@@ -224,6 +286,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
   __shared__ __attribute__((aligned(16))) char sKt[64 * 128];
   __shared__ __attribute__((aligned(16))) char sVr[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sValid[64];
+  __shared__ int sAllValid;
   const int seq = blockIdx.z, head = blockIdx.y;
   const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
   const int q0 = blockIdx.x * 64;
@@ -243,7 +306,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     qf[c] = *(const bf16x8*)(qbase + (long)qrow * rs + c * 32 + g * 8);
     dof[c] = *(const bf16x8*)(dout + (long)(s0 + qrow) * H + head * 64 + c * 32 + g * 8);
   }
-  const float lse_q = lse[(long)head * T + s0 + qrow];
+  const float c2 = scale * LOG2E;
+  const float lse2_q = lse[(long)head * T + s0 + qrow] * LOG2E;
   // delta_q = sum_d dO[q,d] * O[q,d]: this lane holds 16 of the 64 d's; the 4 lane groups sum up.
   // Written out for the dK/dV pass that follows on the same stream.
   float dl_q = 0.f;
@@ -267,16 +331,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
 #pragma unroll
   for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  TileRegs rk, rv;
+  tile_load(rk, kbase, rs, j_lo * 64, slen);
+  tile_load(rv, vbase, rs, j_lo * 64, slen);
   for (int j = j_lo; j <= j_hi; ++j) {
     const int key0 = j * 64;
     __syncthreads();
-    stage_dual(kbase, rs, key0, slen, sKr, sKt);
-    stage_dual(vbase, rs, key0, slen, sVr, nullptr);
+    tile_store(rk, sKr, sKt);
+    tile_store(rv, sVr, nullptr);
+    if (j < j_hi) {
+      tile_load(rk, kbase, rs, key0 + 64, slen);
+      tile_load(rv, vbase, rs, key0 + 64, slen);
+    }
     if (threadIdx.x < 64) {
       const int key = key0 + threadIdx.x;
-      sValid[threadIdx.x] = (key < slen && mask[s0 + key] != 0) ? 1 : 0;
+      const bool v = key < slen && mask[s0 + key] != 0;
+      sValid[threadIdx.x] = v ? 1 : 0;
+      const unsigned long long all = __ballot(v);
+      if (threadIdx.x == 0) sAllValid = (all == ~0ull) ? 1 : 0;
     }
     __syncthreads();
+    const bool clean = sAllValid && band_clean(window, q0 + wave * 16, q0 + wave * 16 + 15, key0, key0 + 63);
     bf16x8 dsb[2];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -288,17 +363,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[c], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[c], dp, 0, 0, 0);
       }
-      const uint32_t vm = *(const uint32_t*)(sValid + kt * 16 + g * 4);
+      if (clean) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + kt * 16 + g * 4 + r;
-        bool ok = (vm >> (8 * r)) & 1;
-        if (window >= 0) {
-          const int dlt = qpos - key;
-          ok = ok && (dlt <= window) && (dlt >= -window);
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp2(fmaf(s[r], c2, -lse2_q));
+          dsb[kt >> 1][(kt & 1) * 4 + r] = f2bf(p * (dp[r] - dl_q));
         }
-        const float p = ok ? __expf(s[r] * scale - lse_q) : 0.f;
-        dsb[kt >> 1][(kt & 1) * 4 + r] = f2bf(p * (dp[r] - dl_q));
+      } else {
+        const uint32_t vm = *(const uint32_t*)(sValid + kt * 16 + g * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + kt * 16 + g * 4 + r;
+          bool ok = (vm >> (8 * r)) & 1;
+          if (window >= 0) {
+            const int dlt = qpos - key;
+            ok = ok && (dlt <= window) && (dlt >= -window);
+          }
+          const float p = ok ? fast_exp2(fmaf(s[r], c2, -lse2_q)) : 0.f;
+          dsb[kt >> 1][(kt & 1) * 4 + r] = f2bf(p * (dp[r] - dl_q));
+        }
       }
     }
 #pragma unroll
@@ -342,6 +425,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
   const int kpos = key0 + wave * 16 + li;
   const int krow = kpos < slen ? kpos : slen - 1;
   const bool kvalid = kpos < slen && mask[s0 + krow] != 0;
+  const bool wave_keys_valid = __ballot(kvalid) == ~0ull;
+  const float c2 = scale * LOG2E;
   bf16x8 kf[2], vf[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -360,18 +445,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
     dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  TileRegs rq, rdo;
+  float r_lse = 0.f, r_del = 0.f;
+  auto load_stats = [&](int q0n) {
+    if (threadIdx.x < 64) {
+      const int q = q0n + threadIdx.x;
+      const int qc = q < slen ? q : slen - 1;
+      r_lse = lse[(long)head * T + s0 + qc] * LOG2E;                 // log2 domain
+      r_del = delta[(long)head * T + s0 + qc];
+    }
+  };
+  tile_load(rq, qbase, rs, i_lo * 64, slen);
+  tile_load(rdo, dobase, H, i_lo * 64, slen);
+  load_stats(i_lo * 64);
   for (int i = i_lo; i <= i_hi; ++i) {
     const int q0 = i * 64;
     __syncthreads();
-    stage_dual(qbase, rs, q0, slen, sQr, sQt);
-    stage_dual(dobase, H, q0, slen, sOr, sOt);
+    tile_store(rq, sQr, sQt);
+    tile_store(rdo, sOr, sOt);
     if (threadIdx.x < 64) {
-      const int q = q0 + threadIdx.x;
-      const int qc = q < slen ? q : slen - 1;
-      sLse[threadIdx.x] = lse[(long)head * T + s0 + qc];
-      sDel[threadIdx.x] = delta[(long)head * T + s0 + qc];
+      sLse[threadIdx.x] = r_lse;
+      sDel[threadIdx.x] = r_del;
+    }
+    if (i < i_hi) {
+      tile_load(rq, qbase, rs, q0 + 64, slen);
+      tile_load(rdo, dobase, H, q0 + 64, slen);
+      load_stats(q0 + 64);
     }
     __syncthreads();
+    // no masking needed when all 64 queries exist, this wave's 16 keys are all valid and in band
+    const bool clean = (q0 + 63 < slen) && wave_keys_valid &&
+                       band_clean(window, q0, q0 + 63, key0 + wave * 16, key0 + wave * 16 + 15);
     bf16x8 pb[2], dsb[2];
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
@@ -387,13 +491,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
       const f32x4 d4 = *(const f32x4*)(sDel + qt * 16 + g * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int q = q0 + qt * 16 + g * 4 + r;
-        bool ok = kvalid && q < slen;
-        if (window >= 0) {
-          const int dlt = q - kpos;
-          ok = ok && (dlt <= window) && (dlt >= -window);
+        float p = fast_exp2(fmaf(s[r], c2, -l4[r]));
+        if (!clean) {
+          const int q = q0 + qt * 16 + g * 4 + r;
+          bool ok = kvalid && q < slen;
+          if (window >= 0) {
+            const int dlt = q - kpos;
+            ok = ok && (dlt <= window) && (dlt >= -window);
+          }
+          p = ok ? p : 0.f;
         }
-        const float p = ok ? __expf(s[r] * scale - l4[r]) : 0.f;
         pb[qt >> 1][(qt & 1) * 4 + r] = f2bf(p);
         dsb[qt >> 1][(qt & 1) * 4 + r] = f2bf(p * (dp[r] - d4[r]));
       }
