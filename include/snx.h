@@ -123,8 +123,24 @@ int snx_gemm_nt_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N
 /* ... fused with the fp32 residual add of hf:331-332: Hout = Hin + bf16(A B^T). */
 int snx_gemm_nt_resid(const void* A, const void* B, const float* Hin, float* Hout, int32_t M, int32_t N, int32_t K,
                       hipStream_t stream);
+/* ... Wqkv fused with apply_rotary_pos_emb (hf:271-280): columns < rope_cols (q and k) rotated. */
+int snx_gemm_nt_rope(const void* A, const void* B, void* C, const float* rope_tab, const int32_t* pos,
+                     int32_t rope_cols, int32_t M, int32_t N, int32_t K, hipStream_t stream);
+/* ... Wi fused with GeGLU (hf:90-91).  B = Wi rows in the interleaved order of snx_cast_geglu_interleave;
+ * U [M,N] = Wi output in that column order (saved for backward), Y [M,N/2] = gelu(a) * g. */
+int snx_gemm_nt_geglu_fwd(const void* A, const void* B_interleaved, void* U, void* Y, int32_t M, int32_t N,
+                          int32_t K, hipStream_t stream);
+/* ... dX of mlp.Wo fused with the GeGLU backward: dy = A B^T [M,N=I]; dU [M,2N] (interleaved). */
+int snx_gemm_nt_geglu_bwd(const void* A, const void* B, const void* U, void* dU, int32_t M, int32_t N, int32_t K,
+                          hipStream_t stream);
+/* fp32 Wi [2I,C] -> bf16 interleaved copy out [2I,C] and/or its transpose out_t [C,2I]: every 64-row
+ * group = [a rows 32q..32q+31 | g rows 32q..32q+31] (so a and its gate meet in one lane of the GEMM). */
+int snx_cast_geglu_interleave(const float* in, void* out, void* out_t, int32_t I, int32_t C, hipStream_t stream);
 /* weight gradient of a Linear: dW[N,K] += dY[M,N]^T X[M,K]  (N, K multiples of 128). */
 int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K, hipStream_t stream);
+/* same with dY's columns in the interleaved GeGLU order; dW rows land in the natural Wi order. */
+int snx_gemm_tn_accum_interleaved(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K,
+                                  hipStream_t stream);
 
 /* LayerNorm without bias (hf:61,312,314,420,487), fp32 in -> bf16 out. */
 int snx_ln_fwd(const float* h, const float* w, void* x_out, int32_t T, int32_t H, float eps, hipStream_t stream);
@@ -154,9 +170,11 @@ int snx_geglu_bwd(const void* u, const void* dy, void* du, int32_t T, int32_t I,
 int snx_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse, int32_t T,
                  int32_t nseq, int32_t max_seqlen, int32_t heads, int32_t head_dim, int32_t window,
                  hipStream_t stream);
+/* rope_tab/pos (both or neither): also apply the backward of apply_rotary_pos_emb to dq, dk. */
 int snx_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
-                 const int64_t* mask, float* delta_scratch /*[heads,T]*/, void* dqkv, int32_t T, int32_t nseq,
-                 int32_t max_seqlen, int32_t heads, int32_t head_dim, int32_t window, hipStream_t stream);
+                 const int64_t* mask, float* delta_scratch /*[heads,T]*/, void* dqkv, const float* rope_tab,
+                 const int32_t* pos, int32_t T, int32_t nseq, int32_t max_seqlen, int32_t heads, int32_t head_dim,
+                 int32_t window, hipStream_t stream);
 
 /* Tied decoder GEMM + SPLADE tail fused (hf:550 + ref:src/model/splade_modern.py:76-86). */
 size_t snx_splade_head_scratch_bytes(int32_t T, int32_t V);

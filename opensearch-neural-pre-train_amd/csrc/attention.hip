@@ -278,10 +278,39 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int dt, int c, int l
   return (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 }
 
+// Epilogue of dQ / dK / dV: this lane holds grad[d = 16*dt + 4g + r] of one token row.  With a
+// RoPE table the transposed rotation (backward of hf:196-219) is applied to the bf16-rounded
+// gradient before the store: the pair (d, d+32) lives in accumulators dt and dt+2 of the same lane.
+__device__ __forceinline__ void store_grad_rows(bf16_t* orow, const f32x4 (&acc)[4], float scale,
+                                                const f32x2* __restrict__ rope_tab, int p, int g) {
+  if (rope_tab) {
+    const f32x2* cs = rope_tab + (long)p * 32 + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      bf16x4 lo, hi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x2 t = cs[dt * 16 + r];
+        const float y1 = rbf(acc[dt][r] * scale), y2 = rbf(acc[dt + 2][r] * scale);
+        lo[r] = f2bf(y1 * t[0] + y2 * t[1]);
+        hi[r] = f2bf(y2 * t[0] - y1 * t[1]);
+      }
+      *(bf16x4*)(orow + dt * 16) = lo;
+      *(bf16x4*)(orow + (dt + 2) * 16) = hi;
+    }
+  } else {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *(bf16x4*)(orow + dt * 16) = (bf16x4){f2bf(acc[dt][0] * scale), f2bf(acc[dt][1] * scale),
+                                            f2bf(acc[dt][2] * scale), f2bf(acc[dt][3] * scale)};
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ delta, const int32_t* __restrict__ cu_seqlens,
-    const int64_t* __restrict__ mask, bf16_t* __restrict__ dqkv, int T, int heads, int window, float scale) {
+    const int64_t* __restrict__ mask, bf16_t* __restrict__ dqkv, const f32x2* __restrict__ rope_tab,
+    const int32_t* __restrict__ pos, int T, int heads, int window, float scale) {
   __shared__ __attribute__((aligned(16))) char sKr[64 * 128];
   __shared__ __attribute__((aligned(16))) char sKt[64 * 128];
   __shared__ __attribute__((aligned(16))) char sVr[64 * 128];
@@ -392,18 +421,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
   }
   if (qpos < slen) {
     bf16_t* orow = dqkv + (long)(s0 + qpos) * rs + head * 64 + g * 4;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      bf16x4 v = {f2bf(dq[d][0] * scale), f2bf(dq[d][1] * scale), f2bf(dq[d][2] * scale), f2bf(dq[d][3] * scale)};
-      *(bf16x4*)(orow + d * 16) = v;
-    }
+    store_grad_rows(orow, dq, scale, rope_tab, pos ? pos[s0 + qpos] : 0, g);
   }
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, const int32_t* __restrict__ cu_seqlens, const int64_t* __restrict__ mask,
-    bf16_t* __restrict__ dqkv, int T, int heads, int window, float scale) {
+    bf16_t* __restrict__ dqkv, const f32x2* __restrict__ rope_tab, const int32_t* __restrict__ pos, int T,
+    int heads, int window, float scale) {
   __shared__ __attribute__((aligned(16))) char sQr[64 * 128];
   __shared__ __attribute__((aligned(16))) char sQt[64 * 128];
   __shared__ __attribute__((aligned(16))) char sOr[64 * 128];
@@ -516,29 +542,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
   if (kpos < slen) {
     bf16_t* krow_out = dqkv + (long)(s0 + kpos) * rs + H + head * 64 + g * 4;
     bf16_t* vrow_out = krow_out + H;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      bf16x4 a = {f2bf(dk[d][0] * scale), f2bf(dk[d][1] * scale), f2bf(dk[d][2] * scale), f2bf(dk[d][3] * scale)};
-      bf16x4 b = {f2bf(dv[d][0]), f2bf(dv[d][1]), f2bf(dv[d][2]), f2bf(dv[d][3])};
-      *(bf16x4*)(krow_out + d * 16) = a;
-      *(bf16x4*)(vrow_out + d * 16) = b;
-    }
+    store_grad_rows(krow_out, dk, scale, rope_tab, pos ? pos[s0 + kpos] : 0, g);
+    store_grad_rows(vrow_out, dv, 1.0f, nullptr, 0, g);
   }
 }
 
 extern "C" int snx_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                             const int32_t* cu_seqlens, const int64_t* mask, float* delta_scratch, void* dqkv,
-                            int32_t T, int32_t nseq, int32_t max_seqlen, int32_t heads, int32_t head_dim,
-                            int32_t window, hipStream_t st) {
+                            const float* rope_tab, const int32_t* pos, int32_t T, int32_t nseq, int32_t max_seqlen,
+                            int32_t heads, int32_t head_dim, int32_t window, hipStream_t st) {
+  if ((rope_tab == nullptr) != (pos == nullptr)) return SNX_E_ARG;
   if (!qkv || !out || !dout || !lse || !cu_seqlens || !mask || !delta_scratch || !dqkv) return SNX_E_ARG;
   if (T <= 0 || nseq <= 0 || max_seqlen <= 0 || heads <= 0 || head_dim != 64) return SNX_E_SHAPE;
   dim3 grid(cdiv(max_seqlen, 64), heads, nseq);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
-                     (const bf16_t*)dout, lse, delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, T, heads, window,
-                     0.125f);
+                     (const bf16_t*)dout, lse, delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv,
+                     (const f32x2*)rope_tab, pos, T, heads, window, 0.125f);
   SNX_CHECK_LAUNCH();
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
-                     delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, T, heads, window, 0.125f);
+                     delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, (const f32x2*)rope_tab, pos, T, heads, window,
+                     0.125f);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }

@@ -39,6 +39,44 @@ __global__ void cast_transpose_bf16_kernel(const float* __restrict__ in, bf16_t*
   }
 }
 
+// GeGLU-interleaved copies of Wi [2I, C]: output row n holds source row
+//   src(n) = (n%64 < 32) ? 32*(n/64) + n%32 : I + 32*(n/64) + n%32
+// so that every 64-row group is [a rows 32q..32q+31 | g rows 32q..32q+31].  out [2I, C] and/or the
+// transposed out_t [C, 2I] (columns in the same interleaved order).
+__device__ __forceinline__ int geglu_src_row(int n, int I) {
+  return ((n & 63) < 32) ? 32 * (n >> 6) + (n & 31) : I + 32 * (n >> 6) + (n & 31);
+}
+
+__global__ void cast_interleave_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
+                                       bf16_t* __restrict__ out_t, int I, int C) {
+  __shared__ float tile[64][65];
+  const int R = 2 * I;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int gr = r0 + r, gc = c0 + tx;
+    const float v = (gr < R && gc < C) ? in[(long)geglu_src_row(gr, I) * C + gc] : 0.f;
+    tile[r][tx] = v;
+    if (out && gr < R && gc < C) out[(long)gr * C + gc] = f2bf(v);
+  }
+  __syncthreads();
+  if (out_t)
+    for (int c = ty; c < 64; c += 4) {
+      const int gc = c0 + c, gr = r0 + tx;
+      if (gc < C && gr < R) out_t[(long)gc * R + gr] = f2bf(tile[tx][c]);
+    }
+}
+
+extern "C" int snx_cast_geglu_interleave(const float* in, void* out, void* out_t, int32_t I, int32_t C,
+                                         hipStream_t st) {
+  if (!in || (!out && !out_t) || I <= 0 || C <= 0) return SNX_E_ARG;
+  if (I % 32) return SNX_E_SHAPE;
+  hipLaunchKernelGGL(cast_interleave_kernel, dim3(cdiv(C, 64), cdiv(2 * I, 64)), dim3(256), 0, st, in, (bf16_t*)out,
+                     (bf16_t*)out_t, I, C);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
 extern "C" int snx_cast_bf16(const float* in, void* out, int64_t n, hipStream_t st) {
   if (!in || !out || n <= 0) return SNX_E_ARG;
   if (((uintptr_t)in & 15) || ((uintptr_t)out & 7)) return SNX_E_ARG;

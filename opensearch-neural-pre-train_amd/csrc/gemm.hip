@@ -2,16 +2,46 @@
 //   C[M,N] = A[M,K] * B[N,K]^T, bf16 operands, fp32 MFMA accumulation, fused epilogues.
 // Replaces the cuBLAS calls behind nn.Linear under autocast(bf16)
 // (transformers modeling_modernbert.py:271,300,90-91,490 via ref:src/model/splade_modern.py:69).
+//
+// Epilogues (the accumulators are "transposed": a lane owns 4 consecutive columns of one row, and
+// the four 16-column tiles j = 0..3 of a wave's 64-column span sit in the SAME lane, so the
+// pairings RoPE (d, d+32) and GeGLU (a, g) need no data movement):
+//   STORE      C = bf16(acc)
+//   RESID      Hout = Hin + bf16(acc)                       (fp32 residual stream, hf:331-332)
+//   ROPE       qkv = bf16(acc), q and k thirds rotated      (apply_rotary_pos_emb, hf:196-219)
+//   GEGLU_FWD  u = bf16(acc) (interleaved layout), y = gelu(a) * g                (hf:90-91)
+//   GEGLU_BWD  dy = bf16(acc); du = GeGLU'(u, dy)            (backward of the above)
+// "Interleaved" Wi layout: per 64-column span, columns 0..31 hold a[32q..32q+31] and columns
+// 32..63 hold g[32q..32q+31] (the weight cache stores Wi's rows in that order).
+//
+// Tried and measured slower on MI355X (kept out of the tree): 3-stage counted-vmcnt pipeline at
+// one workgroup per CU (551 vs 725 TFLOP/s), 256x128 8-wave tiles (623), 32-deep K-tiles in a
+// 4-stage ring (571), persistent workgroups with cross-tile prefetch (neutral), stream-K for dW.
+// Two independent 4-wave workgroups per CU with one barrier per 64-deep K-step win.
 #include "gemm_core.h"
 #include "snx.h"
 
-enum { EPI_STORE_BF16 = 0, EPI_RESID_F32 = 1 };
+enum { EPI_STORE_BF16 = 0, EPI_RESID_F32 = 1, EPI_ROPE = 2, EPI_GEGLU_FWD = 3, EPI_GEGLU_BWD = 4 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int STAGES>
+struct EpiArgs {
+  bf16_t* C;                 // STORE / ROPE: [M,N];  GEGLU_FWD: u [M,N] interleaved;  GEGLU_BWD: du [M,2N] interleaved
+  const float* Hin;          // RESID
+  float* Hout;               // RESID
+  const f32x2* rope_tab;     // ROPE: [max_pos][32] (cos, sin)
+  const int32_t* pos;        // ROPE: [M] position of each row
+  int rope_cols;             // ROPE: columns < rope_cols (= 2*hidden) are rotated
+  bf16_t* Y;                 // GEGLU_FWD: y [M, N/2]
+  const bf16_t* U;           // GEGLU_BWD: u [M, 2N] interleaved
+};
+
+__device__ __forceinline__ bf16x4 pack4(const f32x4 v) { return (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N, int K, int tiles_n, int ntiles,
-    bf16_t* __restrict__ Cb, const float* __restrict__ Hin, float* __restrict__ Hout) {
+    EpiArgs e) {
   using Core = GemmCore<BM, BN, WAVES_M, WAVES_N>;
+  static_assert(Core::WTN == 64, "fused epilogues pair the four 16-column tiles of a 64-column wave span");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
@@ -20,74 +50,140 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
   for (int i = 0; i < Core::MI; ++i)
 #pragma unroll
     for (int j = 0; j < Core::NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (STAGES == 3) Core::template mainloop3<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
-  else Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
-  // transposed accumulators: this lane owns columns col..col+3 of row `row` (8-B / 16-B accesses)
+  Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int g4 = (lane >> 4) * 4;
+  const int span0 = n0 + wn * 64;                    // first column of this wave's 64-column span
 #pragma unroll
   for (int i = 0; i < Core::MI; ++i) {
     const int row = m0 + wm * Core::WTM + i * 16 + (lane & 15);
     if (row >= M) continue;
+    if (EPI == EPI_STORE_BF16 || EPI == EPI_RESID_F32) {
 #pragma unroll
-    for (int j = 0; j < Core::NI; ++j) {
-      const int col = n0 + wn * Core::WTN + j * 16 + (lane >> 4) * 4;
-      if (col >= N) continue;                       // N % 4 == 0: the 4 columns are in or out together
-      const long o = (long)row * N + col;
-      const f32x4 v = acc[i][j];
-      if (EPI == EPI_STORE_BF16) {
-        *(bf16x4*)(Cb + o) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-      } else {                                      // Linear output is bf16, residual stream fp32
-        const f32x4 h = *(const f32x4*)(Hin + o);
-        *(f32x4*)(Hout + o) = (f32x4){h[0] + rbf(v[0]), h[1] + rbf(v[1]), h[2] + rbf(v[2]), h[3] + rbf(v[3])};
+      for (int j = 0; j < Core::NI; ++j) {
+        const int col = span0 + j * 16 + g4;
+        if (col >= N) continue;                       // N % 4 == 0: the 4 columns are in or out together
+        const long o = (long)row * N + col;
+        if (EPI == EPI_STORE_BF16) {
+          *(bf16x4*)(e.C + o) = pack4(acc[i][j]);
+        } else {
+          const f32x4 h = *(const f32x4*)(e.Hin + o), v = acc[i][j];
+          *(f32x4*)(e.Hout + o) = (f32x4){h[0] + rbf(v[0]), h[1] + rbf(v[1]), h[2] + rbf(v[2]), h[3] + rbf(v[3])};
+        }
+      }
+    } else if (EPI == EPI_ROPE) {
+      if (span0 >= N) continue;                       // N % 64 == 0
+      bf16_t* crow = e.C + (long)row * N + span0 + g4;
+      if (span0 < e.rope_cols) {                      // one head of q or k: rotate pairs (d, d+32)
+        const f32x2* cs = e.rope_tab + (long)e.pos[row] * 32 + g4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x4 lo, hi;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x2 t = cs[j * 16 + r];
+            const float x1 = rbf(acc[i][j][r]), x2 = rbf(acc[i][j + 2][r]);   // Linear output is bf16
+            lo[r] = x1 * t[0] - x2 * t[1];
+            hi[r] = x2 * t[0] + x1 * t[1];
+          }
+          *(bf16x4*)(crow + j * 16) = pack4(lo);
+          *(bf16x4*)(crow + (j + 2) * 16) = pack4(hi);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(bf16x4*)(crow + j * 16) = pack4(acc[i][j]);
+      }
+    } else if (EPI == EPI_GEGLU_FWD) {
+      if (span0 >= N) continue;                       // N % 64 == 0
+      bf16_t* urow = e.C + (long)row * N + span0 + g4;
+      bf16_t* yrow = e.Y + (long)row * (N / 2) + (span0 / 2) + g4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x4 a4 = pack4(acc[i][j]), gg4 = pack4(acc[i][j + 2]);
+        *(bf16x4*)(urow + j * 16) = a4;
+        *(bf16x4*)(urow + (j + 2) * 16) = gg4;
+        bf16x4 y4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y4[r] = f2bf(rbf(gelu_f(bf2f(a4[r]))) * bf2f(gg4[r]));
+        *(bf16x4*)(yrow + j * 16) = y4;
+      }
+    } else {                                          // EPI_GEGLU_BWD: this GEMM's output is dy [M, N = I]
+#pragma unroll
+      for (int j = 0; j < Core::NI; ++j) {
+        const int col = span0 + j * 16 + g4;          // natural column c of dy
+        if (col >= N) continue;
+        const long o = (long)row * (2 * N) + 64 * (col >> 5) + (col & 31);
+        const bf16x4 a4 = *(const bf16x4*)(e.U + o), gg4 = *(const bf16x4*)(e.U + o + 32);
+        bf16x4 da, dg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float af = bf2f(a4[r]), gf = bf2f(gg4[r]), df = rbf(acc[i][j][r]);
+          dg[r] = f2bf(df * rbf(gelu_f(af)));
+          da[r] = f2bf(rbf(df * gf) * gelu_grad_f(af));
+        }
+        *(bf16x4*)(e.C + o) = da;
+        *(bf16x4*)(e.C + o + 32) = dg;
       }
     }
   }
 }
 
-static int g_nt_variant = -1;     // -1: auto; 0: 128x128 2-stage; 1: 128x128 3-stage; 2: 256x128 3-stage (tuning knob)
-extern "C" int snx_debug_set_gemm_variant(int32_t v) { g_nt_variant = v; return SNX_OK; }
-
-template <int BM, int BN, int WM, int WN, int EPI, int STAGES>
-static int launch_nt_cfg(const void* A, const void* B, int M, int N, int K, void* Cb, const float* Hin, float* Hout,
-                         hipStream_t st) {
-  using Core = GemmCore<BM, BN, WM, WN>;
+template <int EPI>
+static int launch_nt(const void* A, const void* B, int M, int N, int K, const EpiArgs& e, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0) return SNX_E_SHAPE;
+  if ((EPI == EPI_ROPE || EPI == EPI_GEGLU_FWD) && (N % 64) != 0) return SNX_E_SHAPE;
+  if (EPI == EPI_GEGLU_BWD && (N % 32) != 0) return SNX_E_SHAPE;
+  if (!A || !B) return SNX_E_ARG;
+  constexpr int BM = 128, BN = 128;
+  using Core = GemmCore<BM, BN, 2, 2>;
   const int tm = cdiv(M, BM), tn = cdiv(N, BN);
-  auto kern = gemm_nt_kernel<BM, BN, WM, WN, EPI, STAGES>;
-  const int lds = STAGES == 3 ? Core::LDS_BYTES3 : Core::LDS_BYTES;
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(Core::NTHREADS), lds, st, (const bf16_t*)A, (const bf16_t*)B, M, N, K,
-                     tn, tm * tn, (bf16_t*)Cb, Hin, Hout);
+  auto kern = gemm_nt_kernel<BM, BN, 2, 2, EPI>;
+  hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(Core::NTHREADS), Core::LDS_BYTES, st, (const bf16_t*)A,
+                     (const bf16_t*)B, M, N, K, tn, tm * tn, e);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
-}
-
-template <int EPI>
-static int launch_nt(const void* A, const void* B, int M, int N, int K, void* Cb, const float* Hin, float* Hout,
-                     hipStream_t st) {
-  if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0) return SNX_E_SHAPE;
-  if (!A || !B) return SNX_E_ARG;
-  int v = g_nt_variant;
-  if (v < 0) v = 0;
-  if (v == 2) return launch_nt_cfg<256, 128, 4, 2, EPI, 3>(A, B, M, N, K, Cb, Hin, Hout, st);
-  if (v == 1) return launch_nt_cfg<128, 128, 2, 2, EPI, 3>(A, B, M, N, K, Cb, Hin, Hout, st);
-  return launch_nt_cfg<128, 128, 2, 2, EPI, 2>(A, B, M, N, K, Cb, Hin, Hout, st);
 }
 
 extern "C" int snx_gemm_nt_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K,
                                 hipStream_t stream) {
   if (!C) return SNX_E_ARG;
-  return launch_nt<EPI_STORE_BF16>(A, B, M, N, K, C, nullptr, nullptr, stream);
+  EpiArgs e{};
+  e.C = (bf16_t*)C;
+  return launch_nt<EPI_STORE_BF16>(A, B, M, N, K, e, stream);
 }
 
 extern "C" int snx_gemm_nt_resid(const void* A, const void* B, const float* Hin, float* Hout, int32_t M, int32_t N,
                                  int32_t K, hipStream_t stream) {
   if (!Hin || !Hout) return SNX_E_ARG;
-  return launch_nt<EPI_RESID_F32>(A, B, M, N, K, nullptr, Hin, Hout, stream);
+  EpiArgs e{};
+  e.Hin = Hin; e.Hout = Hout;
+  return launch_nt<EPI_RESID_F32>(A, B, M, N, K, e, stream);
+}
+
+extern "C" int snx_gemm_nt_rope(const void* A, const void* B, void* C, const float* rope_tab, const int32_t* pos,
+                                int32_t rope_cols, int32_t M, int32_t N, int32_t K, hipStream_t stream) {
+  if (!C || !rope_tab || !pos) return SNX_E_ARG;
+  if (rope_cols < 0 || rope_cols > N || (rope_cols % 64) != 0) return SNX_E_SHAPE;
+  EpiArgs e{};
+  e.C = (bf16_t*)C; e.rope_tab = (const f32x2*)rope_tab; e.pos = pos; e.rope_cols = rope_cols;
+  return launch_nt<EPI_ROPE>(A, B, M, N, K, e, stream);
+}
+
+extern "C" int snx_gemm_nt_geglu_fwd(const void* A, const void* B_interleaved, void* U, void* Y, int32_t M,
+                                     int32_t N, int32_t K, hipStream_t stream) {
+  if (!U || !Y) return SNX_E_ARG;
+  EpiArgs e{};
+  e.C = (bf16_t*)U; e.Y = (bf16_t*)Y;
+  return launch_nt<EPI_GEGLU_FWD>(A, B_interleaved, M, N, K, e, stream);
+}
+
+extern "C" int snx_gemm_nt_geglu_bwd(const void* A, const void* B, const void* U, void* dU, int32_t M, int32_t N,
+                                     int32_t K, hipStream_t stream) {
+  if (!U || !dU) return SNX_E_ARG;
+  EpiArgs e{};
+  e.C = (bf16_t*)dU; e.U = (const bf16_t*)U;
+  return launch_nt<EPI_GEGLU_BWD>(A, B, M, N, K, e, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -132,7 +228,7 @@ __device__ __forceinline__ bf16x8 tn_frag(const char* tile, int mb, int cbase, i
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
                                                       float* __restrict__ dW, int M, int N, int K, int tiles_k,
-                                                      int rows_per_split) {
+                                                      int rows_per_split, int interleave_I) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE_BYTES = 64 * 256, STAGE_BYTES = 2 * TILE_BYTES;
   const int lane = threadIdx.x & 63;
@@ -178,7 +274,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+      int n = n0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+      if (interleave_I > 0)                           // dY columns are in the interleaved GeGLU order
+        n = ((n & 63) < 32) ? 32 * (n >> 6) + (n & 31) : interleave_I + 32 * (n >> 6) + (n & 31);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k = k0 + wn * 64 + j * 16 + (lane & 15);
@@ -187,10 +285,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     }
 }
 
-extern "C" int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K,
-                                 hipStream_t st) {
+static int launch_tn(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K, int interleave_I,
+                     hipStream_t st) {
   if (!dY || !X || !dW) return SNX_E_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128)) return SNX_E_SHAPE;
+  if (interleave_I < 0 || (interleave_I > 0 && 2 * interleave_I != N)) return SNX_E_SHAPE;
   const int tiles = (N / 128) * (K / 128);
   // token-range splits: fill (at most) the 512 resident workgroup slots (2 x 64 KiB LDS per CU on
   // 256 CUs); more splits than that only add float-atomic traffic
@@ -202,7 +301,18 @@ extern "C" int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32
   rows = ((rows + 63) / 64) * 64;
   splits = cdiv(M, rows);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 2 * 2 * 64 * 256, st, (const bf16_t*)dY,
-                     (const bf16_t*)X, dW, M, N, K, K / 128, rows);
+                     (const bf16_t*)X, dW, M, N, K, K / 128, rows, interleave_I);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
+}
+
+extern "C" int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K,
+                                 hipStream_t st) {
+  return launch_tn(dY, X, dW, M, N, K, 0, st);
+}
+
+// dY [M, 2I] in the interleaved GeGLU column order -> dW rows in the natural Wi order
+extern "C" int snx_gemm_tn_accum_interleaved(const void* dY, const void* X, float* dW, int32_t M, int32_t N,
+                                             int32_t K, hipStream_t st) {
+  return launch_tn(dY, X, dW, M, N, K, N / 2, st);
 }

@@ -125,49 +125,6 @@ struct GemmCore {
     }
   }
 
-  // Three-stage variant: K-tiles kt+1 and kt+2 are in flight while tile kt is multiplied.  The
-  // wait is a COUNTED vmcnt (the newest tile's DMA stays in flight across the barrier) and the
-  // barrier is a raw s_barrier (__syncthreads() would drain vmcnt to 0).  One barrier per K-step:
-  // after it every wave has (a) seen tile kt land and (b) finished reading tile kt-1, whose buffer
-  // is the one tile kt+2 is staged into.
-  static constexpr int LDS_BYTES3 = 3 * STAGE_BYTES;
-  static constexpr int DMA_PER_STAGE = BM / 8 / NW + BN / 8 / NW;   // LDS-DMA instructions per wave per K-tile
-  template <bool TRANSPOSED = false>
-  static __device__ __forceinline__ void mainloop3(const bf16_t* __restrict__ A, long lda, int m0, int M,
-                                                   const bf16_t* __restrict__ B, long ldb, int n0, int N,
-                                                   int K, char* smem, f32x4 (&acc)[MI][NI]) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int nk = K / BK;
-    stage<BM>(A, lda, m0, M, 0, smem, wave, lane);
-    stage<BN>(B, ldb, n0, N, 0, smem + A_BYTES, wave, lane);
-    if (nk > 1) {
-      stage<BM>(A, lda, m0, M, BK, smem + STAGE_BYTES, wave, lane);
-      stage<BN>(B, ldb, n0, N, BK, smem + STAGE_BYTES + A_BYTES, wave, lane);
-    }
-    int cur = 0;                                      // buffer index of tile kt (kt % 3)
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) {
-        static_assert(DMA_PER_STAGE == 4 || DMA_PER_STAGE == 6 || DMA_PER_STAGE == 8, "add a vmcnt case");
-        if (DMA_PER_STAGE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        if (DMA_PER_STAGE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        if (DMA_PER_STAGE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      if (kt + 2 < nk) {
-        const int nb = cur == 0 ? 2 : cur - 1;        // (kt + 2) % 3
-        char* nxt = smem + nb * STAGE_BYTES;
-        stage<BM>(A, lda, m0, M, (kt + 2) * BK, nxt, wave, lane);
-        stage<BN>(B, ldb, n0, N, (kt + 2) * BK, nxt + A_BYTES, wave, lane);
-      }
-      compute_step<TRANSPOSED>(smem + cur * STAGE_BYTES, wm, wn, lane, acc);
-      cur = cur == 2 ? 0 : cur + 1;
-    }
-  }
-
   // Accumulator element (i, j, r) of this lane is C[row][col] with
   //   row = m0 + wm*WTM + i*16 + (lane>>4)*4 + r,   col = n0 + wn*WTN + j*16 + (lane&15).
   static __device__ __forceinline__ int acc_row(int i, int r) {

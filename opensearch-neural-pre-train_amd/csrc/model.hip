@@ -210,7 +210,7 @@ extern "C" int snx_weight_cache_refresh(const snx_model_desc* d, const void* con
   for (int l = 0; l < d->layers; ++l) {
     RC(both(p.wqkv(l), c.wqkv[l], c.wqkv_t[l], 3 * H, H));
     RC(both(p.wo(l), c.wo[l], c.wo_t[l], H, H));
-    RC(both(p.wi(l), c.wi[l], c.wi_t[l], 2 * I, H));
+    RC(snx_cast_geglu_interleave((const float*)params[p.wi(l)], base + c.wi[l], base + c.wi_t[l], I, H, st));
     RC(both(p.wo_mlp(l), c.wom[l], c.wom_t[l], H, I));
   }
   RC(both(p.head_dense(), c.dense, c.dense_t, H, H));
@@ -261,15 +261,16 @@ extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* par
   for (int l = 0; l < L; ++l) {
     const bool global = (l % d->global_every) == 0;
     if (l > 0) { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l), F(p.attn_norm(l)), sv + s.x_attn[l], T, H, d->ln_eps, st)); }
-    { PROF(PC_GEMM_NT, 2.0 * T * 3 * H * H); RC(snx_gemm_nt_bf16(sv + s.x_attn[l], wc + c.wqkv[l], sv + s.qkv[l], T, 3 * H, H, st)); }
-    { PROF(PC_ROPE, TH * 8); RC(snx_rope_inplace(sv + s.qkv[l], global ? rope_global : rope_local, pos, T, d->heads, 0, st)); }
+    { PROF(PC_GEMM_NT, 2.0 * T * 3 * H * H);      // Wqkv + RoPE fused
+      RC(snx_gemm_nt_rope(sv + s.x_attn[l], wc + c.wqkv[l], sv + s.qkv[l], global ? rope_global : rope_local, pos,
+                          2 * H, T, 3 * H, H, st)); }
     { PROF(PC_ATTN_FWD, 4.0 * TH * (global ? max_seqlen : (2 * d->window + 1 < max_seqlen ? 2 * d->window + 1 : max_seqlen)));
       RC(snx_attn_fwd(sv + s.qkv[l], cu_seqlens, mask, sv + s.attn[l], (float*)(sv + s.lse[l]), T, nseq, max_seqlen,
                       d->heads, d->head_dim, global ? -1 : d->window, st)); }
     { PROF(PC_GEMM_NT_RESID, 2.0 * TH * H); RC(snx_gemm_nt_resid(sv + s.attn[l], wc + c.wo[l], hbuf(2 * l), hbuf(2 * l + 1), T, H, H, st)); }
     { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l + 1), F(p.mlp_norm(l)), sv + s.x_mlp[l], T, H, d->ln_eps, st)); }
-    { PROF(PC_GEMM_NT, 2.0 * T * 2 * I * H); RC(snx_gemm_nt_bf16(sv + s.x_mlp[l], wc + c.wi[l], sv + s.u[l], T, 2 * I, H, st)); }
-    { PROF(PC_GEGLU, (double)T * I * 6); RC(snx_geglu_fwd(sv + s.u[l], sv + s.y[l], T, I, st)); }
+    { PROF(PC_GEMM_NT, 2.0 * T * 2 * I * H);      // Wi + GeGLU fused (u kept in the interleaved column order)
+      RC(snx_gemm_nt_geglu_fwd(sv + s.x_mlp[l], wc + c.wi[l], sv + s.u[l], sv + s.y[l], T, 2 * I, H, st)); }
     { PROF(PC_GEMM_NT_RESID, 2.0 * TH * I); RC(snx_gemm_nt_resid(sv + s.y[l], wc + c.wom[l], hbuf(2 * l + 1), hbuf(2 * l + 2), T, H, I, st)); }
   }
   { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * L), F(p.final_norm()), sv + s.xf, T, H, d->ln_eps, st)); }
@@ -315,7 +316,7 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
   auto G = [&](int idx) { return (float*)grads[idx]; };
   auto hbuf = [&](int i) { return (const float*)(sv + s.h[i]); };
   float* dh = (float*)(sc + b.dh);
-  char *A = sc + b.a, *Bb = sc + b.b, *Cc = sc + b.c, *Wd = sc + b.w;
+  char *A = sc + b.a, *Bb = sc + b.b, *Wd = sc + b.w;
   const long n4 = (long)T * H / 4;
 
   const double TH = (double)T * H;
@@ -334,9 +335,9 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
     const double attn_keys = global ? max_seqlen : (2 * d->window + 1 < max_seqlen ? 2 * d->window + 1 : max_seqlen);
     // ---- MLP:  h[2l+2] = h[2l+1] + Wo( gelu(a) * g ),  [a|g] = Wi( LN(h[2l+1]) )
     { PROF(PC_GEMM_TN, 2.0 * TH * I); RC(snx_gemm_tn_accum(A, sv + s.y[l], G(p.wo_mlp(l)), T, H, I, st)); }
-    { PROF(PC_GEMM_NT, 2.0 * TH * I); RC(snx_gemm_nt_bf16(A, wc + c.wom_t[l], Cc, T, I, H, st)); }   // dy [T,I]
-    { PROF(PC_GEGLU, (double)T * I * 10); RC(snx_geglu_bwd(sv + s.u[l], Cc, Wd, T, I, st)); }        // du [T,2I]
-    { PROF(PC_GEMM_TN, 2.0 * TH * 2 * I); RC(snx_gemm_tn_accum(Wd, sv + s.x_mlp[l], G(p.wi(l)), T, 2 * I, H, st)); }
+    { PROF(PC_GEMM_NT, 2.0 * TH * I);             // dy = dh Wo, GeGLU backward fused -> du [T,2I] (interleaved)
+      RC(snx_gemm_nt_geglu_bwd(A, wc + c.wom_t[l], sv + s.u[l], Wd, T, I, H, st)); }
+    { PROF(PC_GEMM_TN, 2.0 * TH * 2 * I); RC(snx_gemm_tn_accum_interleaved(Wd, sv + s.x_mlp[l], G(p.wi(l)), T, 2 * I, H, st)); }
     { PROF(PC_GEMM_NT, 2.0 * TH * 2 * I); RC(snx_gemm_nt_bf16(Wd, wc + c.wi_t[l], A, T, H, 2 * I, st)); }   // dx [T,H]
     { PROF(PC_LN_BWD, TH * 16); RC(snx_ln_bwd(A, hbuf(2 * l + 1), F(p.mlp_norm(l)), dh, A, G(p.mlp_norm(l)), T, H, d->ln_eps, 0, st)); }
     // ---- attention:  h[2l+1] = h[2l] + Wo( attn( rope( Wqkv( LN(h[2l]) ) ) ) )
@@ -344,9 +345,8 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
     { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(A, wc + c.wo_t[l], Bb, T, H, H, st)); }    // d(attn out)
     { PROF(PC_ATTN_BWD, 10.0 * TH * attn_keys);
       RC(snx_attn_bwd(sv + s.qkv[l], sv + s.attn[l], Bb, (const float*)(sv + s.lse[l]), cu_seqlens, mask,
-                      (float*)(sc + b.delta), Wd, T, nseq, max_seqlen, d->heads, d->head_dim,
-                      global ? -1 : d->window, st)); }
-    { PROF(PC_ROPE, TH * 8); RC(snx_rope_inplace(Wd, global ? rope_global : rope_local, pos, T, d->heads, 1, st)); }
+                      (float*)(sc + b.delta), Wd, global ? rope_global : rope_local, pos, T, nseq, max_seqlen,
+                      d->heads, d->head_dim, global ? -1 : d->window, st)); }      // inverse RoPE fused
     { PROF(PC_GEMM_TN, 2.0 * TH * 3 * H); RC(snx_gemm_tn_accum(Wd, sv + s.x_attn[l], G(p.wqkv(l)), T, 3 * H, H, st)); }
     { PROF(PC_GEMM_NT, 2.0 * TH * 3 * H); RC(snx_gemm_nt_bf16(Wd, wc + c.wqkv_t[l], A, T, H, 3 * H, st)); }   // dx [T,H]
     if (l > 0) {

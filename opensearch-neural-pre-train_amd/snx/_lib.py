@@ -35,7 +35,12 @@ SIGNATURES = {
     "snx_geglu_fwd": (I32, [P, P, I32, I32, P]),
     "snx_geglu_bwd": (I32, [P, P, P, I32, I32, P]),
     "snx_attn_fwd": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
-    "snx_attn_bwd": (I32, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
+    "snx_attn_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
+    "snx_gemm_nt_rope": (I32, [P, P, P, P, P, I32, I32, I32, I32, P]),
+    "snx_gemm_nt_geglu_fwd": (I32, [P, P, P, P, I32, I32, I32, P]),
+    "snx_gemm_nt_geglu_bwd": (I32, [P, P, P, P, I32, I32, I32, P]),
+    "snx_gemm_tn_accum_interleaved": (I32, [P, P, P, I32, I32, I32, P]),
+    "snx_cast_geglu_interleave": (I32, [P, P, P, I32, I32, P]),
     "snx_splade_head_scratch_bytes": (SZ, [I32, I32]),
     "snx_decoder_splade_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),
     "snx_decoder_splade_fwd_ex": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),

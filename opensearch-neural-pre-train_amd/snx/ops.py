@@ -88,6 +88,60 @@ def gemm_tn_accum(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor) -> None:
     check(fn("snx_gemm_tn_accum")(_p(dy), _p(x), _p(dw), M, N, K, _stream()), "snx_gemm_tn_accum")
 
 
+def gemm_nt_rope(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, rope_cols: int):
+    """qkv = rope(A @ B^T) on columns < rope_cols (fused Wqkv + apply_rotary_pos_emb)."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    M, K = a.shape; N = b.shape[0]
+    _chk(table, torch.float32, "table"); _chk(pos, torch.int32, "pos", (M,))
+    if b.shape[1] != K or K % 64 or N % 64 or int(pos.max()) >= table.shape[0]:
+        raise ValueError("gemm_nt_rope: bad shapes")
+    c = torch.empty((M, N), dtype=BF16, device=a.device)
+    check(fn("snx_gemm_nt_rope")(_p(a), _p(b), _p(c), _p(table), _p(pos), rope_cols, M, N, K, _stream()),
+          "snx_gemm_nt_rope")
+    return c
+
+
+def cast_geglu_interleave(wi: torch.Tensor):
+    """fp32 Wi [2I, C] -> (bf16 interleaved [2I, C], bf16 interleaved transposed [C, 2I])."""
+    _chk(wi, torch.float32, "wi")
+    R, Cc = wi.shape
+    out = torch.empty((R, Cc), dtype=BF16, device=wi.device)
+    out_t = torch.empty((Cc, R), dtype=BF16, device=wi.device)
+    check(fn("snx_cast_geglu_interleave")(_p(wi), _p(out), _p(out_t), R // 2, Cc, _stream()), "snx_cast_geglu_interleave")
+    return out, out_t
+
+
+def gemm_nt_geglu_fwd(a: torch.Tensor, wi_interleaved: torch.Tensor):
+    """-> (u [M, 2I] interleaved, y [M, I])."""
+    _chk(a, BF16, "a"); _chk(wi_interleaved, BF16, "wi")
+    M, K = a.shape; N = wi_interleaved.shape[0]
+    if wi_interleaved.shape[1] != K or K % 64 or N % 64:
+        raise ValueError("gemm_nt_geglu_fwd: bad shapes")
+    u = torch.empty((M, N), dtype=BF16, device=a.device)
+    y = torch.empty((M, N // 2), dtype=BF16, device=a.device)
+    check(fn("snx_gemm_nt_geglu_fwd")(_p(a), _p(wi_interleaved), _p(u), _p(y), M, N, K, _stream()), "snx_gemm_nt_geglu_fwd")
+    return u, y
+
+
+def gemm_nt_geglu_bwd(a: torch.Tensor, b: torch.Tensor, u: torch.Tensor):
+    """dy = A @ B^T [M, I];  -> du [M, 2I] (interleaved) = GeGLU backward(u, dy)."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    M, K = a.shape; N = b.shape[0]
+    _chk(u, BF16, "u", (M, 2 * N))
+    if b.shape[1] != K or K % 64 or N % 32:
+        raise ValueError("gemm_nt_geglu_bwd: bad shapes")
+    du = torch.empty_like(u)
+    check(fn("snx_gemm_nt_geglu_bwd")(_p(a), _p(b), _p(u), _p(du), M, N, K, _stream()), "snx_gemm_nt_geglu_bwd")
+    return du
+
+
+def gemm_tn_accum_interleaved(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor) -> None:
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x")
+    M, N = dy.shape; K = x.shape[1]
+    _chk(dw, torch.float32, "dw", (N, K))
+    check(fn("snx_gemm_tn_accum_interleaved")(_p(dy), _p(x), _p(dw), M, N, K, _stream()), "snx_gemm_tn_accum_interleaved")
+
+
 # ----------------------------------------------------------------------------- norms
 def ln_fwd(h: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     _chk(h, torch.float32, "h"); T, H = h.shape
@@ -209,8 +263,10 @@ def attn_fwd(qkv: torch.Tensor, cu: torch.Tensor, mask: torch.Tensor, max_seqlen
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, cu, mask, max_seqlen: int, heads: int, window: int, validate: bool = True):
-    """Returns dqkv [T, 3*heads*64] bf16 (gradients w.r.t. the post-RoPE q, k and v)."""
+def attn_bwd(qkv, out, dout, lse, cu, mask, max_seqlen: int, heads: int, window: int, validate: bool = True,
+             rope_table: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None):
+    """Returns dqkv [T, 3*heads*64] bf16: gradients w.r.t. the post-RoPE q, k and v, or -- with
+    rope_table/pos -- w.r.t. the pre-RoPE projections (inverse rotation fused into the epilogue)."""
     _chk(qkv, BF16, "qkv"); T = qkv.shape[0]
     _chk(out, BF16, "out", (T, heads * 64)); _chk(dout, BF16, "dout", (T, heads * 64))
     _chk(lse, torch.float32, "lse", (heads, T)); _chk(mask, torch.int64, "mask")
@@ -219,8 +275,11 @@ def attn_bwd(qkv, out, dout, lse, cu, mask, max_seqlen: int, heads: int, window:
     nseq = cu.numel() - 1
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((heads, T), dtype=torch.float32, device=qkv.device)
-    check(fn("snx_attn_bwd")(_p(qkv), _p(out), _p(dout), _p(lse), _p(cu), _p(mask), _p(delta), _p(dqkv), T, nseq,
-                             max_seqlen, heads, 64, window, _stream()), "snx_attn_bwd")
+    if rope_table is not None:
+        _chk(rope_table, torch.float32, "rope_table"); _chk(pos, torch.int32, "pos", (T,))
+    check(fn("snx_attn_bwd")(_p(qkv), _p(out), _p(dout), _p(lse), _p(cu), _p(mask), _p(delta), _p(dqkv),
+                             _p(rope_table), _p(pos), T, nseq, max_seqlen, heads, 64, window, _stream()),
+          "snx_attn_bwd")
     return dqkv
 
 

@@ -383,3 +383,81 @@ def test_splade_bwd(dev, B, S, V, H):
         cos = float(gg @ rr / (gg.norm() * rr.norm() + 1e-30))
         rel = float((gg - rr).norm() / (rr.norm() + 1e-30))
         assert cos > 0.999 and rel < 2e-2, (name, cos, rel)
+
+
+def _interleave_cols(x, I):
+    """natural [.., 2I] (a | g) -> interleaved column order used by the fused GeGLU GEMMs."""
+    n = torch.arange(2 * I, device=x.device)
+    src = torch.where((n % 64) < 32, 32 * (n // 64) + (n % 32), I + 32 * (n // 64) + (n % 32))
+    return x[..., src]
+
+
+def test_fused_wqkv_rope_epilogue(dev):
+    ops = _ops()
+    B, S, heads = 3, 70, 4
+    H = heads * 64
+    T = B * S
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(T, H, generator=g).to(dev).to(BF16)
+    w = (torch.randn(3 * H, H, generator=g) * 0.05).to(dev).to(BF16)
+    pos = torch.arange(S, dtype=torch.int32).repeat(B).to(dev)
+    tab = ops.rope_table(128, 64, 10000.0, dev)
+    fused = ops.gemm_nt_rope(x, w, tab, pos, 2 * H)
+    ref = ops.gemm_nt(x, w)
+    ops.rope_inplace(ref, tab, pos, heads)
+    assert torch.equal(fused[:, 2 * H:], ref[:, 2 * H:])                      # v third untouched
+    _ulp_close(fused, ref, "fused rope", frac_exact=0.995)                    # FMA contraction may differ by 1 ulp
+
+
+@pytest.mark.parametrize("T,H,I", [(300, 256, 384), (1000, 768, 1152)])
+def test_fused_geglu_epilogues(dev, T, H, I):
+    ops = _ops()
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(T, H, generator=g).to(dev).to(BF16)
+    wi = (torch.randn(2 * I, H, generator=g) * 0.05).to(dev)
+    wom = (torch.randn(H, I, generator=g) * 0.05).to(dev)
+    dh = (torch.randn(T, H, generator=g) * 0.1).to(dev).to(BF16)
+    wi_il, wi_il_t = ops.cast_geglu_interleave(wi)
+    assert torch.equal(wi_il, _interleave_cols(wi.to(BF16).t(), I).t().contiguous())
+    assert torch.equal(wi_il_t, wi_il.t().contiguous())
+    # forward: fused == gemm + geglu, u in interleaved order
+    u_ref = ops.gemm_nt(x, wi.to(BF16))
+    y_ref = ops.geglu_fwd(u_ref)
+    u, y = ops.gemm_nt_geglu_fwd(x, wi_il)
+    assert torch.equal(u, _interleave_cols(u_ref, I)) and torch.equal(y, y_ref)
+    # backward: dy = dh @ Wo (as NT with Wo^T), du = GeGLU'(u, dy)
+    wom_t = ops.cast_transpose_bf16(wom)                     # [I, H]
+    dy = ops.gemm_nt(dh, wom_t)
+    du_ref = ops.geglu_bwd(u_ref, dy)
+    du = ops.gemm_nt_geglu_bwd(dh, wom_t, u)
+    assert torch.equal(du, _interleave_cols(du_ref, I))
+    # dW through the interleaved TN GEMM lands in the natural row order
+    dw_ref = torch.zeros(2 * I, H, device=dev)
+    dw = torch.zeros(2 * I, H, device=dev)
+    ops.gemm_tn_accum(du_ref, x, dw_ref)
+    ops.gemm_tn_accum_interleaved(du, x, dw)
+    assert torch.allclose(dw, dw_ref, rtol=1e-4, atol=1e-4)
+    # dX through the interleaved transposed cache
+    dx_ref = ops.gemm_nt(du_ref, ops.cast_transpose_bf16(wi))
+    dx = ops.gemm_nt(du, wi_il_t)
+    _ulp_close(dx, dx_ref, "dx interleaved", frac_exact=0.95)
+
+
+def test_attention_bwd_fused_inverse_rope(dev):
+    ops = _ops()
+    B, S, heads = 2, 130, 2
+    T = B * S
+    lens, mask = _ragged(B, S, 77)
+    g = torch.Generator().manual_seed(41)
+    qkv = (torch.randn(T, 3 * heads * 64, generator=g) * 1.2).to(dev).to(BF16)
+    dout = (torch.randn(T, heads * 64, generator=g) * 0.5).to(dev).to(BF16)
+    cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
+    md = mask.reshape(-1).to(dev)
+    pos = torch.arange(S, dtype=torch.int32).repeat(B).to(dev)
+    tab = ops.rope_table(256, 64, 160000.0, dev)
+    out, lse = ops.attn_fwd(qkv, cu, md, S, heads, 64)
+    ref = ops.attn_bwd(qkv, out, dout, lse, cu, md, S, heads, 64)
+    ops.rope_inplace(ref, tab, pos, heads, inverse=True)
+    fused = ops.attn_bwd(qkv, out, dout, lse, cu, md, S, heads, 64, rope_table=tab, pos=pos)
+    assert torch.equal(fused[:, 2 * heads * 64:], ref[:, 2 * heads * 64:])
+    _ulp_close(fused, ref, "fused inverse rope", frac_exact=0.995)

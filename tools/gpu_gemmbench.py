@@ -33,3 +33,7 @@ for (M, N, K) in [(16384, 2304, 768), (16384, 768, 768), (16384, 768, 1152), (40
     ms = timeit(lambda: ops.gemm_tn_accum(dy, x, dw)); res[f"tn_{M}x{N}x{K}"] = (round(ms * 1e3, 1), round(2.0 * M * N * K / ms / 1e9))
     ms = timeit(lambda: torch.matmul(dy.t(), x)); res[f"torch_tn_{M}x{N}x{K}"] = (round(ms * 1e3, 1), round(2.0 * M * N * K / ms / 1e9))
 for k, v in res.items(): print(f"{k:28s} {v[0]:8.1f} us {v[1]:6d} TF/s")
+# correctness spot-check of the selected variant
+a = torch.randn(1000, 768, device=dev).to(BF16); b = (torch.randn(640, 768, device=dev) * 0.05).to(BF16)
+c = ops.gemm_nt(a, b); ref = (a.float() @ b.float().t()).to(BF16)
+print("variant", VAR, "max abs diff vs torch", float((c.float() - ref.float()).abs().max()), "exact frac", float((c == ref).float().mean()))
