@@ -255,19 +255,32 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
       tn_stage(dY, N, m_begin + (t + 1) * 64, m_end, n0, nxt, wave, lane);
       tn_stage(X, K, m_begin + (t + 1) * 64, m_end, k0, nxt + TILE_BYTES, wave, lane);
     }
+    // all 32 transposed fragment reads (64 ds_read_b64_tr_b16) up front, then 1 MFMA : 2 reads
+    bf16x8 a[2][4], b[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = tn_frag(cur, kk * 32, wm * 64 + i * 16, lane);
+      for (int i = 0; i < 4; ++i) a[kk][i] = tn_frag(cur, kk * 32, wm * 64 + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = tn_frag(cur + TILE_BYTES, kk * 32, wn * 64 + j * 16, lane);
+      for (int j = 0; j < 4; ++j) b[kk][j] = tn_frag(cur + TILE_BYTES, kk * 32, wn * 64 + j * 16, lane);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+#if SNX_GEMM_SCHED
+#pragma unroll
+    for (int q = 0; q < 16; ++q) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+#endif
   }
   // acc[i][j][r] = dW[n0 + wm*64 + i*16 + 4g + r][k0 + wn*64 + j*16 + (lane&15)]
 #pragma unroll

@@ -15,11 +15,7 @@ def timeit(f, n=30, warm=5):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 res = {}
-import ctypes
-from snx._lib import lib
-setv = lib().snx_debug_set_gemm_variant
-VAR = int(os.environ.get("GEMM_VARIANT", "-1"))
-setv(VAR)
+VAR = 0
 for (M, N, K) in [(16384, 2304, 768), (16384, 768, 768), (16384, 768, 1152), (16384, 768, 2304), (16384, 1152, 768), (4096, 2304, 768), (4096, 768, 768)]:
     a = torch.randn(M, K, device=dev).to(BF16); b = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
     h = torch.randn(M, N, device=dev)
