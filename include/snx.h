@@ -192,6 +192,16 @@ int snx_splade_bwd(const float* g, const uint32_t* keys, const void* Hd, const v
                    void* dHd, float* gradE, float* gradb, void* scratch, int32_t T, int32_t nseq,
                    int32_t max_seqlen, int32_t V, int32_t H, hipStream_t stream);
 
+/* ---- fused optimizer step (ref:src/train/cli/train_v33_ddp.py:367-374: clip_grad_norm_ + AdamW) ----
+ * All four arrays are flat fp32 [n] (16-byte aligned).  hp [host] = {lr, beta1, beta2, eps, weight_decay,
+ * max_norm (<= 0: no clipping)}; `step` is the 1-based optimizer step (bias correction); elements in
+ * [nodecay_begin, nodecay_end) get weight_decay 0 (the reference's no-decay group = decoder.bias);
+ * norm_out [1] receives the pre-clip global L2 norm; scratch: snx_adamw_scratch_bytes(). */
+size_t snx_adamw_scratch_bytes(void);
+int snx_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        const float* hp /*[host]*/, int64_t step, int64_t nodecay_begin, int64_t nodecay_end,
+                        float* norm_out, void* scratch, hipStream_t stream);
+
 /* ---- optional per-kernel-class timing inside the model entry points (HIP events recorded on
  * the launch stream around every kernel class; off by default).  snx_prof_read synchronises on
  * the recorded events and returns, per class, elapsed ms, launch count and algorithmic work

@@ -57,6 +57,8 @@ SIGNATURES = {
     "snx_model_forward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P]),
     "snx_model_backward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P]),
     "snx_param_count": (I32, [P]),
+    "snx_adamw_scratch_bytes": (SZ, []),
+    "snx_adamw_clip_step": (I32, [P, P, P, P, I64, P, I64, I64, I64, P, P, P]),
     "snx_version": (I32, []),
     "snx_prof_enable": (I32, [I32]),
     "snx_prof_num_classes": (I32, []),

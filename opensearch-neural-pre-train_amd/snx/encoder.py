@@ -74,6 +74,7 @@ class EncoderRuntime:
         self._seq_cache: Dict[Tuple[int, int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
         self.direct_grads = False
         self.flat_grad: Optional[torch.Tensor] = None
+        self.flat_param: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ parameter plumbing
     def _device(self):
@@ -131,6 +132,30 @@ class EncoderRuntime:
             for p in self.params:
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
                 off += p.numel()
+
+    def flatten_parameters(self):
+        """Re-home every parameter into ONE contiguous fp32 buffer (canonical order); the
+        nn.Parameters become views of it.  Lets the optimizer run as a single fused kernel."""
+        dev = self._device()
+        if self.flat_param is not None and self.flat_param.device == dev and \
+                all(p.data_ptr() == self.flat_param.data_ptr() + 4 * o for p, o in zip(self.params, self._flat_offs)):
+            return
+        total = sum(p.numel() for p in self.params)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        offs, off = [], 0
+        with torch.no_grad():
+            for p in self.params:
+                v = flat[off:off + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                offs.append(off)
+                off += p.numel()
+        self.flat_param, self._flat_offs = flat, offs
+        self._ptr_key = None
+
+    def mark_weights_dirty(self):
+        """Parameters were modified behind torch's back (fused optimizer): refresh the bf16 cache."""
+        self._wcache_key = None
 
     def zero_grads(self):
         if self.flat_grad is not None:

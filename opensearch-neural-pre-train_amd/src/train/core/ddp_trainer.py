@@ -102,9 +102,11 @@ def unwrap(model: nn.Module) -> nn.Module:
 
 
 # ------------------------------------------------------------------------------------ optimizer
-def build_optimizer(model: nn.Module, config: V33Config) -> AdamW:
+def build_optimizer(model: nn.Module, config: V33Config):
     """ref:train_v33_ddp.py:560-581.  The no-decay substrings match only ``decoder.bias`` under
-    ModernBERT naming, so LayerNorm weights ARE decayed (quirk kept on purpose)."""
+    ModernBERT naming, so LayerNorm weights ARE decayed (quirk kept on purpose).  Under
+    ``NativeDataParallel`` the same groups drive the fused clip+AdamW HIP kernel
+    (``snx.optim.FusedAdamW``, same state-dict layout); SNX_FUSED_ADAMW=0 forces torch's AdamW."""
     no_decay = ["bias", "LayerNorm.weight", "layer_norm.weight"]
     named = list(model.named_parameters())
     groups = [
@@ -112,6 +114,9 @@ def build_optimizer(model: nn.Module, config: V33Config) -> AdamW:
          "weight_decay": config.training.weight_decay},
         {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0},
     ]
+    if isinstance(model, NativeDataParallel) and os.environ.get("SNX_FUSED_ADAMW", "1") != "0":
+        from snx.optim import FusedAdamW
+        return FusedAdamW(model.module.runtime, groups, lr=config.training.learning_rate)
     return AdamW(groups, lr=config.training.learning_rate)
 
 
@@ -229,8 +234,11 @@ def optimizer_step(model, optimizer, scheduler, config: V33Config) -> None:
     """clip -> AdamW -> LR schedule -> zero grads (ref:train_v33_ddp.py:367-373)."""
     if isinstance(model, NativeDataParallel):
         model.sync_gradients()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), config.training.gradient_clip)
-    optimizer.step()
+    if hasattr(optimizer, "grad_norm"):                       # snx.optim.FusedAdamW: clip + AdamW in one pass
+        optimizer.step(max_norm=config.training.gradient_clip)
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), config.training.gradient_clip)
+        optimizer.step()
     scheduler.step()
     if isinstance(model, NativeDataParallel):
         model.zero_grad()

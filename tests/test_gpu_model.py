@@ -342,3 +342,49 @@ def test_forward_many_equals_separate_passes(dev):
     for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         cos, rel = _grad_stats(p2.grad, p1.grad)
         assert cos > 0.99999 and rel < 2e-3, (n1, cos, rel)      # fp32 atomics order only
+
+
+def test_fused_adamw_matches_torch_adamw(dev):
+    """snx_adamw_clip_step == clip_grad_norm_ + torch.optim.AdamW (wd grouping quirk, bias
+    correction, clipping active and inactive), and the state dicts are interchangeable."""
+    from oracle import splade_oracle as O
+    from snx.optim import FusedAdamW
+    from src.train.config.v33 import V33Config
+    from src.train.core import ddp_trainer as T
+    cfg = _small_cfg()
+    params = O.init_params(cfg, seed=11)
+    m1, m2 = _build_model(cfg, params, dev), _build_model(cfg, params, dev)
+    conf = V33Config()
+    conf.training.learning_rate = 1e-2
+    w2 = T.NativeDataParallel(m2)
+    o1, o2 = T.build_optimizer(m1, conf), T.build_optimizer(w2, conf)
+    assert isinstance(o2, FusedAdamW) and not isinstance(o1, FusedAdamW)
+    s1, s2 = T.build_scheduler(o1, 2, 10), T.build_scheduler(o2, 2, 10)
+    gen = torch.Generator().manual_seed(0)
+    for it in range(4):
+        scale = 10.0 if it % 2 == 0 else 1e-3          # clipping on / off
+        for p1, p2 in zip(m1.parameters(), m2.parameters()):
+            g = (torch.randn(p1.shape, generator=gen) * scale).to(dev)
+            p1.grad = g.clone()
+            p2.grad.copy_(g)
+        n1 = torch.nn.utils.clip_grad_norm_(m1.parameters(), 1.0)
+        o1.step(); s1.step()
+        T.optimizer_step(w2, o2, s2, conf)
+        assert float(o2.grad_norm) == pytest.approx(float(n1), rel=1e-5)
+        for (n_, p1), p2 in zip(m1.named_parameters(), m2.parameters()):
+            assert torch.allclose(p1, p2, rtol=2e-5, atol=2e-7), (it, n_)
+        assert float(m2.runtime.flat_grad.abs().max()) == 0.0
+    sd1, sd2 = o1.state_dict(), o2.state_dict()
+    assert sd1["param_groups"][1]["weight_decay"] == sd2["param_groups"][1]["weight_decay"] == 0.0
+    for k in sd1["state"]:
+        assert float(sd1["state"][k]["step"]) == float(sd2["state"][k]["step"]) == 4.0
+        assert torch.allclose(sd1["state"][k]["exp_avg_sq"], sd2["state"][k]["exp_avg_sq"], rtol=1e-4, atol=1e-12)
+    o2.load_state_dict(sd1)                              # torch AdamW state loads into the fused optimizer
+    assert o2._steps == 4 and torch.allclose(o2.state[m2.model.head.dense.weight]["exp_avg"],
+                                             o1.state[m1.model.head.dense.weight]["exp_avg"])
+    # the forward sees the updated weights (bf16 cache refreshed after the fused step)
+    ids, mask = O.synth_ids(2, 16, cfg, torch.Generator().manual_seed(1), ragged=True)
+    with torch.no_grad():
+        a, _ = m1(ids.to(dev), mask.to(dev))
+        b, _ = m2(ids.to(dev), mask.to(dev))
+    assert (a - b).abs().max().item() < 2e-2
