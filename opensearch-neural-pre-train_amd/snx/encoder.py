@@ -165,12 +165,15 @@ class EncoderRuntime:
         return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
     # ------------------------------------------------------------------ forward / backward
-    def forward_impl(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool):
-        return self.forward_many_impl([(input_ids, attention_mask)], save)
+    def forward_impl(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool, lengths=None):
+        return self.forward_many_impl([(input_ids, attention_mask)], save, lengths)
 
-    def forward_many_impl(self, pairs, save: bool):
+    def forward_many_impl(self, pairs, save: bool, lengths=None):
         """One native forward over several [B_i, S_i] batches laid end to end (sequence groups).
-        -> sparse [sum B_i, V], token_weights [sum B_i*S_i] (flat), arena, aux."""
+        -> sparse [sum B_i, V], token_weights [sum B_i*S_i] (flat, padded layout), arena, aux.
+        ``lengths`` (optional, one CPU int tensor [B_i] per pair, right-padded inputs): run UNPADDED
+        -- only the valid tokens are gathered and computed (the kernels take cu_seqlens); the
+        lengths come from the host-side collator output, so no device sync is needed."""
         dev = self._device()
         shapes = []
         for ids, mask in pairs:
@@ -187,23 +190,51 @@ class EncoderRuntime:
         else:
             ids = torch.cat([p[0].to(torch.int64).reshape(-1) for p in pairs])
             mask = torch.cat([p[1].to(torch.int64).reshape(-1) for p in pairs])
-        key = (tuple(shapes), str(dev))
-        lay = self._seq_cache.get(key)
-        if lay is None:
-            cu, pos, groups, t0, s0 = [0], [], [len(shapes)], 0, 0
-            for B, S in shapes:
-                cu += [t0 + (b + 1) * S for b in range(B)]
-                pos.append(torch.arange(S, dtype=torch.int32).repeat(B))
-                groups += [s0, B, S]
-                t0 += B * S
-                s0 += B
-            lay = (torch.tensor(cu, dtype=torch.int32).to(dev), torch.cat(pos).to(dev),
-                   (C.c_int32 * len(groups))(*groups))
-            self._seq_cache[key] = lay
-        cu, pos, groups = lay
-        T = sum(B * S for B, S in shapes)
+        T_pad = sum(B * S for B, S in shapes)
         nseq = sum(B for B, _ in shapes)
-        smax = max(S for _, S in shapes)
+        scatter = None
+        if lengths is not None:
+            if len(lengths) != len(shapes):
+                raise ValueError("one lengths tensor per input pair")
+            cu, pos, idx, groups, t0, p0, s0 = [0], [], [], [len(shapes)], 0, 0, 0
+            for (B, S), ln in zip(shapes, lengths):
+                ln = torch.as_tensor(ln, dtype=torch.int64, device="cpu")
+                if ln.numel() != B or int(ln.min()) < 1 or int(ln.max()) > S:
+                    raise ValueError("lengths must be in [1, seq_len] for every sequence")
+                valid = (torch.arange(S)[None, :] < ln[:, None])
+                idx.append(valid.view(-1).nonzero().view(-1) + p0)
+                pos.append(torch.arange(S, dtype=torch.int32)[None, :].expand(B, S)[valid])
+                for n in ln.tolist():
+                    t0 += n
+                    cu.append(t0)
+                groups += [s0, B, int(ln.max())]
+                p0 += B * S
+                s0 += B
+            scatter = torch.cat(idx).to(dev, non_blocking=True)
+            ids = ids[scatter]
+            mask = torch.ones_like(ids)
+            cu = torch.tensor(cu, dtype=torch.int32).to(dev, non_blocking=True)
+            pos = torch.cat(pos).contiguous().to(dev, non_blocking=True)
+            groups = (C.c_int32 * len(groups))(*groups)
+            T = t0
+            smax = max(groups[3 + 3 * i] for i in range(len(shapes)))
+        else:
+            key = (tuple(shapes), str(dev))
+            lay = self._seq_cache.get(key)
+            if lay is None:
+                cu, pos, groups, t0, s0 = [0], [], [len(shapes)], 0, 0
+                for B, S in shapes:
+                    cu += [t0 + (b + 1) * S for b in range(B)]
+                    pos.append(torch.arange(S, dtype=torch.int32).repeat(B))
+                    groups += [s0, B, S]
+                    t0 += B * S
+                    s0 += B
+                lay = (torch.tensor(cu, dtype=torch.int32).to(dev), torch.cat(pos).to(dev),
+                       (C.c_int32 * len(groups))(*groups))
+                self._seq_cache[key] = lay
+            cu, pos, groups = lay
+            T = T_pad
+            smax = max(S for _, S in shapes)
         rg, rl = self._rope_tables(max(smax, 64), dev)
         wc = self._weights()
         nbytes = fn("snx_model_workspace_bytes")(C.byref(self._desc), T, nseq, int(save))
@@ -212,8 +243,12 @@ class EncoderRuntime:
         tw = torch.empty((T,), dtype=torch.float32, device=dev)
         check(fn("snx_model_forward")(C.byref(self._desc), self._param_ptrs(), _p(wc), _p(ids), _p(mask), _p(cu),
                                       _p(pos), _p(rg), _p(rl), _p(saved), _p(sparse), _p(tw),
-                                      groups if len(shapes) > 1 else None, T, nseq, smax,
+                                      groups if (len(shapes) > 1 or lengths is not None) else None, T, nseq, smax,
                                       SNX_FWD_SAVE_FOR_BACKWARD if save else 0, _stream()), "snx_model_forward")
+        if scatter is not None:                      # token_weights back to the padded layout (0 at padding)
+            tw_full = torch.zeros((T_pad,), dtype=torch.float32, device=dev)
+            tw_full[scatter] = tw
+            tw = tw_full
         aux = (ids, mask, cu, pos, rg, rl, T, nseq, smax)
         return sparse, tw, saved, aux
 
@@ -253,14 +288,15 @@ class EncoderRuntime:
         (out,) = self.forward_many([(input_ids, attention_mask)])
         return out
 
-    def forward_many(self, pairs):
-        """[(ids [B_i,S_i], mask)] -> [(sparse_repr [B_i,V], token_weights [B_i,S_i])], one native pass."""
+    def forward_many(self, pairs, lengths=None):
+        """[(ids [B_i,S_i], mask)] -> [(sparse_repr [B_i,V], token_weights [B_i,S_i])], one native pass.
+        ``lengths``: optional per-pair CPU length tensors -> unpadded (varlen) execution."""
         pairs = list(pairs)
         flat = [t for p in pairs for t in p]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.params):
-            sparse, tw = _SpladeEncodeFn.apply(self, len(pairs), *flat, *self.params)
+            sparse, tw = _SpladeEncodeFn.apply(self, len(pairs), lengths, *flat, *self.params)
         else:
-            sparse, tw, _, _ = self.forward_many_impl(pairs, save=False)
+            sparse, tw, _, _ = self.forward_many_impl(pairs, save=False, lengths=lengths)
         out, r0, t0 = [], 0, 0
         for ids, _ in pairs:
             B, S = ids.shape
@@ -272,10 +308,10 @@ class EncoderRuntime:
 
 class _SpladeEncodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rt: EncoderRuntime, n_pairs: int, *args):
+    def forward(ctx, rt: EncoderRuntime, n_pairs: int, lengths, *args):
         pairs = [(args[2 * i], args[2 * i + 1]) for i in range(n_pairs)]
-        ctx.n_in = 2 * n_pairs
-        sparse, tw, saved, aux = rt.forward_many_impl(pairs, save=True)
+        ctx.n_in = 2 * n_pairs + 1
+        sparse, tw, saved, aux = rt.forward_many_impl(pairs, save=True, lengths=lengths)
         ctx.rt, ctx.saved_arena, ctx.aux = rt, saved, aux
         rt.last_ctx = (saved, aux)          # debugging / parity tests: routing of the latest forward
         ctx.mark_non_differentiable(tw)

@@ -246,12 +246,14 @@ class SPLADEModernBERT(nn.Module):
         ``token_type_ids`` is accepted and ignored (ref:splade_modern.py:54,63)."""
         return self._runtime(input_ids, attention_mask)
 
-    def forward_many(self, batches):
+    def forward_many(self, batches, lengths=None):
         """Extension (not in the reference): encode several (input_ids, attention_mask) batches of
         different sequence length -- e.g. the query, positive and negative batch of one training
         micro-step -- in ONE native pass.  Results are identical to separate ``forward`` calls
-        (sequences never interact); larger GEMMs, a third of the launches."""
-        return self._runtime.forward_many(batches)
+        (sequences never interact); larger GEMMs, a third of the launches.
+        ``lengths`` (one CPU int tensor per batch, right-padded inputs) switches to UNPADDED execution:
+        padded positions are never computed (rank 2 of SURVEY.md §8(f))."""
+        return self._runtime.forward_many(batches, lengths)
 
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         return self.forward(input_ids, attention_mask)[0]

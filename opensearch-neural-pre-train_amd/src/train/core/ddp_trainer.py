@@ -193,10 +193,30 @@ def _fuse_passes(model) -> bool:
         os.environ.get("SNX_FUSED_PASSES", "1") != "0"
 
 
+def _packed_lengths(batch: dict):
+    """Sequence lengths for unpadded execution, taken from the collator's CPU masks (no device sync).
+    None when the masks are already on the device, not right-padded, or fully dense, or SNX_PACK=0."""
+    if os.environ.get("SNX_PACK", "1") == "0":
+        return None
+    out, total, valid = [], 0, 0
+    for key in ("query", "positive", "negative"):
+        m = batch[key + "_attention_mask"]
+        if m.device.type != "cpu":
+            return None
+        ln = m.sum(dim=1)
+        if int(ln.min()) < 1 or not torch.equal(m != 0, torch.arange(m.shape[1])[None, :] < ln[:, None]):
+            return None
+        out.append(ln)
+        total += m.numel()
+        valid += int(ln.sum())
+    return out if valid < total else None
+
+
 def micro_step(model, loss_fn: SPLADELossV33, batch: dict, global_step: int, device: torch.device,
                grad_accum: int, cross_gpu_negatives: bool = False):
     """One micro-batch: three encoder passes, loss, backward (ref:train_v33_ddp.py:321-364)."""
     nb = device.type == "cuda"
+    lengths = _packed_lengths(batch) if _fuse_passes(model) else None
     q_ids = batch["query_input_ids"].to(device, non_blocking=nb)
     q_mask = batch["query_attention_mask"].to(device, non_blocking=nb)
     p_ids = batch["positive_input_ids"].to(device, non_blocking=nb)
@@ -212,7 +232,7 @@ def micro_step(model, loss_fn: SPLADELossV33, batch: dict, global_step: int, dev
     with autocast(device_type=device.type, dtype=torch.bfloat16, enabled=nb):
         if _fuse_passes(model):
             (anchor_repr, _), (positive_repr, _), (negative_repr, _) = unwrap(model).forward_many(
-                [(q_ids, q_mask), (p_ids, p_mask), (n_ids, n_mask)])
+                [(q_ids, q_mask), (p_ids, p_mask), (n_ids, n_mask)], lengths)
         else:
             anchor_repr, _ = model(q_ids, q_mask)
             positive_repr, _ = model(p_ids, p_mask)

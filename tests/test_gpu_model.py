@@ -388,3 +388,29 @@ def test_fused_adamw_matches_torch_adamw(dev):
         a, _ = m1(ids.to(dev), mask.to(dev))
         b, _ = m2(ids.to(dev), mask.to(dev))
     assert (a - b).abs().max().item() < 2e-2
+
+
+def test_unpadded_execution_equals_padded(dev):
+    """varlen path: only valid tokens are computed; outputs identical, gradients equal up to fp32
+    atomic order; token_weights come back in the padded layout with zeros at padding."""
+    from oracle import splade_oracle as O
+    cfg = _small_cfg()
+    params = O.perturb_params(O.init_params(cfg, seed=3), seed=4, scale=2.0, bias_mean=-0.1)
+    gen = torch.Generator().manual_seed(66)
+    b = O.synth_batch(5, 40, 150, cfg, gen, k=1, ragged=True)
+    tags = ("query", "positive", "negative")
+    pairs = [(b[t + "_input_ids"].to(dev), b[t + "_attention_mask"].to(dev)) for t in tags]
+    lengths = [b[t + "_attention_mask"].sum(1) for t in tags]
+    m1, m2 = _build_model(cfg, params, dev), _build_model(cfg, params, dev)
+    pad = m1.forward_many(pairs)
+    pk = m2.forward_many(pairs, lengths)
+    w = [torch.randn_like(s[0]) for s in pad]
+    sum((s[0] * wi).sum() for s, wi in zip(pad, w)).backward()
+    sum((s[0] * wi).sum() for s, wi in zip(pk, w)).backward()
+    for (s1, t1), (s2, t2) in zip(pad, pk):
+        assert torch.equal(s1, s2) and torch.equal(t1, t2)
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        cos, rel = _grad_stats(p2.grad, p1.grad)
+        assert cos > 0.99999 and rel < 2e-3, (n1, cos, rel)
+    with pytest.raises(ValueError):
+        m2.forward_many(pairs, [lengths[0] * 0, lengths[1], lengths[2]])
