@@ -414,3 +414,64 @@ def test_unpadded_execution_equals_padded(dev):
         assert cos > 0.99999 and rel < 2e-3, (n1, cos, rel)
     with pytest.raises(ValueError):
         m2.forward_many(pairs, [lengths[0] * 0, lengths[1], lengths[2]])
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_train_epoch_vs_oracle_loop(dev, native):
+    """rows a14/a15: the trainer's micro-batch loop (accumulate 4, clip, AdamW with the wd-grouping
+    quirk, cosine warm-up LR, lambda schedule on global_step) on the HIP path vs the oracle's
+    restated loop in emulated-bf16 mode: 8 micro-steps = 2 optimizer steps."""
+    from torch.utils.data import DataLoader, Dataset
+    from oracle import splade_oracle as O
+    from src.model.losses import SPLADELossV33
+    from src.train.config.v33 import V33Config
+    from src.train.core import ddp_trainer as T
+
+    cfg = _small_cfg()
+    params = O.perturb_params(O.init_params(cfg, seed=3), seed=4, scale=2.0, bias_mean=-0.1)
+    gen = torch.Generator().manual_seed(2024)
+    batches = [O.synth_batch(4, 24, 70, cfg, gen, k=1, ragged=True) for _ in range(8)]
+    conf = V33Config()
+    conf.training.gradient_accumulation_steps = 4
+    conf.training.learning_rate = 2e-3
+    conf.training.log_every_n_steps = 1
+    conf.loss.flops_warmup_steps = 4
+    conf.loss.temperature = 20.0
+    lc = O.LossConfig(lambda_q=conf.loss.lambda_q, lambda_d=conf.loss.lambda_d, temperature=20.0,
+                      flops_warmup_steps=4, lambda_initial_ratio=conf.loss.lambda_initial_ratio)
+    st = O.TrainState({n: p.clone() for n, p in params.items()})
+    ref_losses, _, gs_ref = O.train_micro_steps(cfg, lc, st, batches, grad_accum=4, base_lr=2e-3, wd=0.01, clip=1.0,
+                                                warmup=1, total_steps=4, global_step=0, mode="bf16")
+
+    class DS(Dataset):
+        def __len__(self):
+            return len(batches)
+
+        def __getitem__(self, i):
+            return batches[i]
+    dl = DataLoader(DS(), batch_size=None, shuffle=False)
+    model = _build_model(cfg, params, dev)
+    if native:
+        model = T.NativeDataParallel(model)
+    loss_fn = SPLADELossV33(lambda_q=conf.loss.lambda_q, lambda_d=conf.loss.lambda_d, temperature=20.0,
+                            flops_warmup_steps=4, lambda_initial_ratio=conf.loss.lambda_initial_ratio).to(dev)
+    rec = []
+    loss_fn.register_forward_hook(lambda m, i, o: rec.append(o[0].detach()))
+    opt = T.build_optimizer(model, conf)
+    sch = T.build_scheduler(opt, 1, 4)
+    avg, gs = T.train_epoch(model, dl, loss_fn, opt, sch, conf, epoch=1, global_step=0, device=dev)
+    assert gs == gs_ref == 2
+    got = [float(x) for x in rec]
+    assert avg == pytest.approx(sum(got) / 8, rel=1e-5)
+    for i, (a, b) in enumerate(zip(got, ref_losses)):
+        assert a == pytest.approx(b, rel=(5e-3 if i < 4 else 3e-2)), (i, got, ref_losses)
+    # the two optimizer steps moved the weights the same way
+    inner = T.unwrap(model)
+    num = den1 = den2 = 0.0
+    for n_, p in inner.named_parameters():
+        d_got = (p.detach().cpu() - params[n_]).double().flatten()
+        d_ref = (st.params[n_] - params[n_]).double().flatten()
+        num += float(d_got @ d_ref); den1 += float(d_got @ d_got); den2 += float(d_ref @ d_ref)
+    cos = num / ((den1 * den2) ** 0.5)
+    _report(f"train_epoch_native{int(native)}", {"losses": got, "ref": ref_losses, "update_cos": cos})
+    assert cos > 0.9, cos
