@@ -120,6 +120,8 @@ int snx_cast_transpose_bf16(const float* in, void* out, int32_t R, int32_t C, hi
 
 /* nn.Linear under autocast (hf:271,300,90-91,490): C[M,N] = A[M,K] B[N,K]^T, bf16, fp32 acc. */
 int snx_gemm_nt_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, hipStream_t stream);
+/* same contract, 256x256 ping-pong kernel (one 8-wave workgroup per CU; see csrc/gemm256.hip). */
+int snx_gemm_nt256_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, hipStream_t stream);
 /* ... fused with the fp32 residual add of hf:331-332: Hout = Hin + bf16(A B^T). */
 int snx_gemm_nt_resid(const void* A, const void* B, const float* Hin, float* Hout, int32_t M, int32_t N, int32_t K,
                       hipStream_t stream);

@@ -23,6 +23,7 @@ SIGNATURES = {
     "snx_cast_bf16": (I32, [P, P, I64, P]),
     "snx_cast_transpose_bf16": (I32, [P, P, I32, I32, P]),
     "snx_gemm_nt_bf16": (I32, [P, P, P, I32, I32, I32, P]),
+    "snx_gemm_nt256_bf16": (I32, [P, P, P, I32, I32, I32, P]),
     "snx_gemm_nt_resid": (I32, [P, P, P, P, I32, I32, I32, P]),
     "snx_gemm_tn_accum": (I32, [P, P, P, I32, I32, I32, P]),
     "snx_ln_fwd": (I32, [P, P, P, I32, I32, F32, P]),

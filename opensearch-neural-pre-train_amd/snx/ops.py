@@ -64,6 +64,18 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return c
 
 
+def gemm_nt256(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Same as gemm_nt on the 256x256 ping-pong kernel."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    M, K = a.shape
+    N, K2 = b.shape
+    if K != K2 or K % 64:
+        raise ValueError("gemm_nt256: bad K")
+    c = torch.empty((M, N), dtype=BF16, device=a.device)
+    check(fn("snx_gemm_nt256_bf16")(_p(a), _p(b), _p(c), M, N, K, _stream()), "snx_gemm_nt256_bf16")
+    return c
+
+
 def gemm_nt_resid(a: torch.Tensor, b: torch.Tensor, h_in: torch.Tensor) -> torch.Tensor:
     """h_out = h_in + bf16(A @ B^T)  (fp32 residual stream)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b")
