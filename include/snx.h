@@ -92,8 +92,8 @@ int snx_model_forward(const snx_model_desc* d, const void* const* params /*[host
 int snx_model_backward(const snx_model_desc* d, const void* const* params /*[host]*/, void* const* grads /*[host]*/,
                        const void* wcache, const int64_t* ids, const int64_t* mask, const int32_t* cu_seqlens,
                        const int32_t* pos, const float* rope_global, const float* rope_local, const void* saved,
-                       const float* g_sparse, void* scratch, int32_t T, int32_t nseq, int32_t max_seqlen,
-                       hipStream_t stream);
+                       const float* g_sparse, void* scratch, const int32_t* groups /*[host] or NULL, as forward*/,
+                       int32_t T, int32_t nseq, int32_t max_seqlen, hipStream_t stream);
 
 /* ---- SPLADELossV33 (ref:src/model/losses.py:183-297) ------------------------------------- */
 /* dims [host] = {B, Bp, k, V, label_off, bf16_mm}: q [B,V], p [Bp,V] (Bp > B: all-gathered
@@ -172,11 +172,20 @@ int snx_geglu_bwd(const void* u, const void* dy, void* du, int32_t T, int32_t I,
 int snx_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse, int32_t T,
                  int32_t nseq, int32_t max_seqlen, int32_t heads, int32_t head_dim, int32_t window,
                  hipStream_t stream);
+/* _ex: `groups` [host] = {n, (seq_begin, nseq, max_len) x n}, n <= 8, consecutive sequence groups with their own
+ * maximum length (NULL: one group of max_seqlen) -- only sizes the launch, results are identical. */
+int snx_attn_fwd_ex(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse,
+                    const int32_t* groups, int32_t T, int32_t nseq, int32_t max_seqlen, int32_t heads,
+                    int32_t head_dim, int32_t window, hipStream_t stream);
 /* rope_tab/pos (both or neither): also apply the backward of apply_rotary_pos_emb to dq, dk. */
 int snx_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
                  const int64_t* mask, float* delta_scratch /*[heads,T]*/, void* dqkv, const float* rope_tab,
                  const int32_t* pos, int32_t T, int32_t nseq, int32_t max_seqlen, int32_t heads, int32_t head_dim,
                  int32_t window, hipStream_t stream);
+int snx_attn_bwd_ex(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
+                    const int64_t* mask, float* delta_scratch /*[heads,T]*/, void* dqkv, const float* rope_tab,
+                    const int32_t* pos, const int32_t* groups, int32_t T, int32_t nseq, int32_t max_seqlen,
+                    int32_t heads, int32_t head_dim, int32_t window, hipStream_t stream);
 
 /* Tied decoder GEMM + SPLADE tail fused (hf:550 + ref:src/model/splade_modern.py:76-86). */
 size_t snx_splade_head_scratch_bytes(int32_t T, int32_t V);

@@ -25,6 +25,68 @@
 // probability costs one FMA + one v_exp.
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Block schedule (speed only).  Blocks b and b+8 share an XCD and its L2.  The unit of placement is
+// one (sequence, head) pair: all its 64-row tiles go to ONE XCD (K/V, or Q/dO in the dK/dV pass, are
+// then fetched from HBM once instead of once per tile: ~2x the algorithmic bytes at ~5 TB/s of fabric
+// traffic before), and consecutive units are dealt round-robin over the XCDs.  Sequence GROUPS (the
+// 64-token queries and 256-token documents of a fused pass) each get the tile count their own
+// max length needs: a workgroup that only finds "tile beyond my sequence" still has to be launched
+// behind the resident ones, and 2304 of those cost ~15 us per backward kernel.  Longest group first.
+#define SNX_ATTN_MAX_GROUPS 8
+struct AttnSched {
+  int n;
+  int seq0[SNX_ATTN_MAX_GROUPS], units[SNX_ATTN_MAX_GROUPS], ntile[SNX_ATTN_MAX_GROUPS];
+  int kend[SNX_ATTN_MAX_GROUPS];      // exclusive prefix end of the group in per-XCD block index space
+};
+struct AttnBlock { int tile, head, seq; bool live; };
+__device__ __forceinline__ AttnBlock attn_block(const AttnSched& sc, int heads) {
+  const int xcd = blockIdx.x & 7;
+  int k = blockIdx.x >> 3;
+  int g = 0, k0 = 0;
+#pragma unroll
+  for (int i = 0; i < SNX_ATTN_MAX_GROUPS - 1; ++i)
+    if (i + 1 < sc.n && k >= sc.kend[i]) { g = i + 1; k0 = sc.kend[i]; }
+  k -= k0;
+  const int nt = sc.ntile[g];
+  const int unit = (k / nt) * 8 + xcd;
+  AttnBlock b;
+  b.tile = k % nt;
+  b.head = unit % heads;
+  b.seq = sc.seq0[g] + unit / heads;
+  b.live = unit < sc.units[g];
+  return b;
+}
+
+// groups = {n, (seq_begin, nseq, max_len) x n} on the host, or NULL for one group of nseq sequences.
+static int attn_sched_build(AttnSched& sc, long& grid, const int32_t* groups, int nseq, int max_seqlen, int heads) {
+  const int32_t one[4] = {1, 0, nseq, max_seqlen};
+  const int32_t* g = groups ? groups : one;
+  if (g[0] < 1 || g[0] > SNX_ATTN_MAX_GROUPS) return SNX_E_ARG;
+  int order[SNX_ATTN_MAX_GROUPS];
+  int covered = 0;
+  for (int i = 0; i < g[0]; ++i) {
+    order[i] = i;
+    if (g[1 + 3 * i] != covered || g[2 + 3 * i] <= 0 || g[3 + 3 * i] <= 0 || g[3 + 3 * i] > max_seqlen) return SNX_E_ARG;
+    covered += g[2 + 3 * i];
+  }
+  if (covered != nseq) return SNX_E_ARG;
+  for (int i = 1; i < g[0]; ++i)                      // insertion sort, longest max_len first
+    for (int j = i; j > 0 && g[3 + 3 * order[j]] > g[3 + 3 * order[j - 1]]; --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  sc.n = g[0];
+  long k = 0;
+  for (int i = 0; i < SNX_ATTN_MAX_GROUPS; ++i) {
+    if (i < g[0]) {
+      const int32_t* e = g + 1 + 3 * order[i];
+      sc.seq0[i] = e[0]; sc.units[i] = e[1] * heads; sc.ntile[i] = cdiv(e[2], 64);
+      k += (long)cdiv(sc.units[i], 8) * sc.ntile[i];
+    } else { sc.seq0[i] = 0; sc.units[i] = 0; sc.ntile[i] = 1; }
+    if (k > 0x0fffffffL) return SNX_E_SHAPE;
+    sc.kend[i] = (int)k;
+  }
+  grid = 8 * k;
+  return SNX_OK;
+}
+
 // true when every (query, key) pair of a 16-query x 64-key (or 64-query x 16-key) block lies inside
 // the band |q - k| <= window, so the per-element band test can be skipped (wave-uniform).
 __device__ __forceinline__ bool band_clean(int window, int a_lo, int a_hi, int b_lo, int b_hi) {
@@ -83,14 +145,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                                                        const int32_t* __restrict__ cu_seqlens,
                                                        const int64_t* __restrict__ mask, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int T, int heads, int window,
-                                                       float scale) {
+                                                       float scale, const AttnSched sched) {
   __shared__ __attribute__((aligned(16))) char sK[64 * 128];
   __shared__ __attribute__((aligned(16))) char sV[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sValid[64];
   __shared__ int sAllValid;
-  const int seq = blockIdx.z, head = blockIdx.y;
+  const AttnBlock blk = attn_block(sched, heads);
+  if (!blk.live) return;
+  const int seq = blk.seq, head = blk.head;
   const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
-  const int q0 = blockIdx.x * 64;
+  const int q0 = blk.tile * 64;
   if (q0 >= slen) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -230,16 +294,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   }
 }
 
+extern "C" int snx_attn_fwd_ex(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse,
+                               const int32_t* groups, int32_t T, int32_t nseq, int32_t max_seqlen, int32_t heads,
+                               int32_t head_dim, int32_t window, hipStream_t st) {
+  if (!qkv || !cu_seqlens || !mask || !out || !lse || T <= 0 || nseq <= 0 || max_seqlen <= 0) return SNX_E_ARG;
+  if (head_dim != 64 || heads <= 0) return SNX_E_SHAPE;
+  AttnSched sc;
+  long grid;
+  const int rc = attn_sched_build(sc, grid, groups, nseq, max_seqlen, heads);
+  if (rc != SNX_OK) return rc;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)qkv, cu_seqlens, mask,
+                     (bf16_t*)out, lse, T, heads, window, 0.125f, sc);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
 extern "C" int snx_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse,
                             int32_t T, int32_t nseq, int32_t max_seqlen, int32_t heads, int32_t head_dim,
                             int32_t window, hipStream_t st) {
-  if (!qkv || !cu_seqlens || !mask || !out || !lse || T <= 0 || nseq <= 0 || max_seqlen <= 0) return SNX_E_ARG;
-  if (head_dim != 64 || heads <= 0) return SNX_E_SHAPE;
-  dim3 grid(cdiv(max_seqlen, 64), heads, nseq);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, cu_seqlens, mask, (bf16_t*)out,
-                     lse, T, heads, window, 0.125f);
-  SNX_CHECK_LAUNCH();
-  return SNX_OK;
+  return snx_attn_fwd_ex(qkv, cu_seqlens, mask, out, lse, nullptr, T, nseq, max_seqlen, heads, head_dim, window, st);
 }
 
 // ==========================================================================================
@@ -310,15 +383,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ delta, const int32_t* __restrict__ cu_seqlens,
     const int64_t* __restrict__ mask, bf16_t* __restrict__ dqkv, const f32x2* __restrict__ rope_tab,
-    const int32_t* __restrict__ pos, int T, int heads, int window, float scale) {
+    const int32_t* __restrict__ pos, int T, int heads, int window, float scale, const AttnSched sched) {
   __shared__ __attribute__((aligned(16))) char sKr[64 * 128];
   __shared__ __attribute__((aligned(16))) char sKt[64 * 128];
   __shared__ __attribute__((aligned(16))) char sVr[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sValid[64];
   __shared__ int sAllValid;
-  const int seq = blockIdx.z, head = blockIdx.y;
+  const AttnBlock blk = attn_block(sched, heads);
+  if (!blk.live) return;
+  const int seq = blk.seq, head = blk.head;
   const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
-  const int q0 = blockIdx.x * 64;
+  const int q0 = blk.tile * 64;
   if (q0 >= slen) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -429,16 +504,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, const int32_t* __restrict__ cu_seqlens, const int64_t* __restrict__ mask,
     bf16_t* __restrict__ dqkv, const f32x2* __restrict__ rope_tab, const int32_t* __restrict__ pos, int T,
-    int heads, int window, float scale) {
+    int heads, int window, float scale, const AttnSched sched) {
   __shared__ __attribute__((aligned(16))) char sQr[64 * 128];
   __shared__ __attribute__((aligned(16))) char sQt[64 * 128];
   __shared__ __attribute__((aligned(16))) char sOr[64 * 128];
   __shared__ __attribute__((aligned(16))) char sOt[64 * 128];
   __shared__ __attribute__((aligned(16))) float sLse[64];
   __shared__ __attribute__((aligned(16))) float sDel[64];
-  const int seq = blockIdx.z, head = blockIdx.y;
+  const AttnBlock blk = attn_block(sched, heads);
+  if (!blk.live) return;
+  const int seq = blk.seq, head = blk.head;
   const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
-  const int key0 = blockIdx.x * 64;
+  const int key0 = blk.tile * 64;
   if (key0 >= slen) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -547,21 +624,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
   }
 }
 
+extern "C" int snx_attn_bwd_ex(const void* qkv, const void* out, const void* dout, const float* lse,
+                               const int32_t* cu_seqlens, const int64_t* mask, float* delta_scratch, void* dqkv,
+                               const float* rope_tab, const int32_t* pos, const int32_t* groups, int32_t T,
+                               int32_t nseq, int32_t max_seqlen, int32_t heads, int32_t head_dim, int32_t window,
+                               hipStream_t st) {
+  if ((rope_tab == nullptr) != (pos == nullptr)) return SNX_E_ARG;
+  if (!qkv || !out || !dout || !lse || !cu_seqlens || !mask || !delta_scratch || !dqkv) return SNX_E_ARG;
+  if (T <= 0 || nseq <= 0 || max_seqlen <= 0 || heads <= 0 || head_dim != 64) return SNX_E_SHAPE;
+  AttnSched sc;
+  long grid_l;
+  const int rc = attn_sched_build(sc, grid_l, groups, nseq, max_seqlen, heads);
+  if (rc != SNX_OK) return rc;
+  const dim3 grid((unsigned)grid_l);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                     (const bf16_t*)dout, lse, delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv,
+                     (const f32x2*)rope_tab, pos, T, heads, window, 0.125f, sc);
+  SNX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                     delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, (const f32x2*)rope_tab, pos, T, heads, window,
+                     0.125f, sc);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
 extern "C" int snx_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                             const int32_t* cu_seqlens, const int64_t* mask, float* delta_scratch, void* dqkv,
                             const float* rope_tab, const int32_t* pos, int32_t T, int32_t nseq, int32_t max_seqlen,
                             int32_t heads, int32_t head_dim, int32_t window, hipStream_t st) {
-  if ((rope_tab == nullptr) != (pos == nullptr)) return SNX_E_ARG;
-  if (!qkv || !out || !dout || !lse || !cu_seqlens || !mask || !delta_scratch || !dqkv) return SNX_E_ARG;
-  if (T <= 0 || nseq <= 0 || max_seqlen <= 0 || heads <= 0 || head_dim != 64) return SNX_E_SHAPE;
-  dim3 grid(cdiv(max_seqlen, 64), heads, nseq);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
-                     (const bf16_t*)dout, lse, delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv,
-                     (const f32x2*)rope_tab, pos, T, heads, window, 0.125f);
-  SNX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
-                     delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, (const f32x2*)rope_tab, pos, T, heads, window,
-                     0.125f);
-  SNX_CHECK_LAUNCH();
-  return SNX_OK;
+  return snx_attn_bwd_ex(qkv, out, dout, lse, cu_seqlens, mask, delta_scratch, dqkv, rope_tab, pos, nullptr, T, nseq,
+                         max_seqlen, heads, head_dim, window, st);
 }

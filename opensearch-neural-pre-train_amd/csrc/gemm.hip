@@ -228,14 +228,19 @@ __device__ __forceinline__ bf16x8 tn_frag(const char* tile, int mb, int cbase, i
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
                                                       float* __restrict__ dW, int M, int N, int K, int tiles_k,
-                                                      int rows_per_split, int interleave_I) {
+                                                      int ntiles, int rows_per_split, int interleave_I) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE_BYTES = 64 * 256, STAGE_BYTES = 2 * TILE_BYTES;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = (blockIdx.x / tiles_k) * 128, k0 = (blockIdx.x % tiles_k) * 128;
-  const int m_begin = blockIdx.y * rows_per_split;
+  // XCD-contiguous order over the (token split, output tile) sequence: the workgroups that share an
+  // XCD's L2 work on the SAME token range (neighbouring tiles), so each slice of dY / X is pulled
+  // from HBM by one XCD only (measured before: 4x the algorithmic bytes, ~5 TB/s of fabric traffic).
+  const int work = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_id = work % ntiles, split = work / ntiles;
+  const int n0 = (tile_id / tiles_k) * 128, k0 = (tile_id % tiles_k) * 128;
+  const int m_begin = split * rows_per_split;
   const int m_end = min(M, m_begin + rows_per_split);
   if (m_begin >= m_end) return;
   const int nsteps = (m_end - m_begin + 63) / 64;
@@ -313,8 +318,8 @@ static int launch_tn(const void* dY, const void* X, float* dW, int32_t M, int32_
   int rows = cdiv(M, splits);
   rows = ((rows + 63) / 64) * 64;
   splits = cdiv(M, rows);
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 2 * 2 * 64 * 256, st, (const bf16_t*)dY,
-                     (const bf16_t*)X, dW, M, N, K, K / 128, rows, interleave_I);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 2 * 2 * 64 * 256, st, (const bf16_t*)dY,
+                     (const bf16_t*)X, dW, M, N, K, K / 128, tiles, rows, interleave_I);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }

@@ -265,8 +265,8 @@ extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* par
       RC(snx_gemm_nt_rope(sv + s.x_attn[l], wc + c.wqkv[l], sv + s.qkv[l], global ? rope_global : rope_local, pos,
                           2 * H, T, 3 * H, H, st)); }
     { PROF(PC_ATTN_FWD, 4.0 * TH * (global ? max_seqlen : (2 * d->window + 1 < max_seqlen ? 2 * d->window + 1 : max_seqlen)));
-      RC(snx_attn_fwd(sv + s.qkv[l], cu_seqlens, mask, sv + s.attn[l], (float*)(sv + s.lse[l]), T, nseq, max_seqlen,
-                      d->heads, d->head_dim, global ? -1 : d->window, st)); }
+      RC(snx_attn_fwd_ex(sv + s.qkv[l], cu_seqlens, mask, sv + s.attn[l], (float*)(sv + s.lse[l]), groups, T, nseq,
+                         max_seqlen, d->heads, d->head_dim, global ? -1 : d->window, st)); }
     { PROF(PC_GEMM_NT_RESID, 2.0 * TH * H); RC(snx_gemm_nt_resid(sv + s.attn[l], wc + c.wo[l], hbuf(2 * l), hbuf(2 * l + 1), T, H, H, st)); }
     { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l + 1), F(p.mlp_norm(l)), sv + s.x_mlp[l], T, H, d->ln_eps, st)); }
     { PROF(PC_GEMM_NT, 2.0 * T * 2 * I * H);      // Wi + GeGLU fused (u kept in the interleaved column order)
@@ -297,7 +297,8 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
                                   const void* wcache, const int64_t* ids, const int64_t* mask,
                                   const int32_t* cu_seqlens, const int32_t* pos, const float* rope_global,
                                   const float* rope_local, const void* saved, const float* g_sparse, void* scratch,
-                                  int32_t T, int32_t nseq, int32_t max_seqlen, hipStream_t st) {
+                                  const int32_t* groups, int32_t T, int32_t nseq, int32_t max_seqlen,
+                                  hipStream_t st) {
   if (!desc_ok(d)) return SNX_E_SHAPE;
   if (!params || !grads || !wcache || !ids || !mask || !cu_seqlens || !pos || !rope_global || !rope_local || !saved ||
       !g_sparse || !scratch || T <= 0 || nseq <= 0 || max_seqlen <= 0)
@@ -344,9 +345,9 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
     { PROF(PC_GEMM_TN, 2.0 * TH * H); RC(snx_gemm_tn_accum(A, sv + s.attn[l], G(p.wo(l)), T, H, H, st)); }
     { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(A, wc + c.wo_t[l], Bb, T, H, H, st)); }    // d(attn out)
     { PROF(PC_ATTN_BWD, 10.0 * TH * attn_keys);
-      RC(snx_attn_bwd(sv + s.qkv[l], sv + s.attn[l], Bb, (const float*)(sv + s.lse[l]), cu_seqlens, mask,
-                      (float*)(sc + b.delta), Wd, global ? rope_global : rope_local, pos, T, nseq, max_seqlen,
-                      d->heads, d->head_dim, global ? -1 : d->window, st)); }      // inverse RoPE fused
+      RC(snx_attn_bwd_ex(sv + s.qkv[l], sv + s.attn[l], Bb, (const float*)(sv + s.lse[l]), cu_seqlens, mask,
+                         (float*)(sc + b.delta), Wd, global ? rope_global : rope_local, pos, groups, T, nseq,
+                         max_seqlen, d->heads, d->head_dim, global ? -1 : d->window, st)); }      // inverse RoPE fused
     { PROF(PC_GEMM_TN, 2.0 * TH * 3 * H); RC(snx_gemm_tn_accum(Wd, sv + s.x_attn[l], G(p.wqkv(l)), T, 3 * H, H, st)); }
     { PROF(PC_GEMM_NT, 2.0 * TH * 3 * H); RC(snx_gemm_nt_bf16(Wd, wc + c.wqkv_t[l], A, T, H, 3 * H, st)); }   // dx [T,H]
     if (l > 0) {

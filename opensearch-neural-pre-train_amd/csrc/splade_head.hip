@@ -15,19 +15,35 @@
 #include "gemm_core.h"
 #include "snx.h"
 
+#ifndef SNX_DEC_GROUP
+#define SNX_DEC_GROUP 8
+#endif
+
 template <int BM>
 __global__ __launch_bounds__(256) void decoder_splade_kernel(
     const bf16_t* __restrict__ Hd, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ cu_seqlens, const int64_t* __restrict__ mask, float* __restrict__ sparse,
     uint32_t* __restrict__ keys, unsigned short* __restrict__ rowpart, int T, int V, int K, int n_tiles,
-    int total_tiles) {
+    int total_tiles, int nseq) {
   constexpr int BN = 128;
   using Core = GemmCore<BM, BN, 2, 2>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t* sBest = (uint32_t*)(smem + Core::LDS_BYTES);           // [2][BN]
   uint32_t* sRow = sBest + 2 * BN;                                 // [2][BM]
-  const int tile = xcd_remap(blockIdx.x, total_tiles);
-  const int seq = tile / n_tiles, nt = tile % n_tiles;
+  // Work order (speed only).  Blocks b and b+8 share an XCD (and its L2).  Sequences are taken in
+  // GROUPS of SNX_DEC_GROUP; group g is placed on XCD g % 8 and, inside it, ids walk vocab tiles with
+  // the group's sequences innermost.  The ~64 workgroups resident on one XCD therefore cover
+  // (group sequences) x (a few vocab tiles): a W_E tile fetched into that L2 serves the whole group
+  // instead of one sequence (W_E was re-streamed once per sequence before: ~9.7 GB of fabric traffic
+  // per 192-sequence launch) while the group's Hd rows (G x S x 1.5 KB) stay resident; dealing the
+  // groups round-robin keeps the XCDs balanced when short (query) and long (document) sequences
+  // share a launch.
+  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int per_group = SNX_DEC_GROUP * n_tiles;
+  const int grp = (k / per_group) * 8 + xcd, within = k % per_group;
+  const int gsz = min(SNX_DEC_GROUP, nseq - grp * SNX_DEC_GROUP);
+  if (gsz <= 0 || within >= gsz * n_tiles) return;
+  const int nt = within / gsz, seq = grp * SNX_DEC_GROUP + (within - nt * gsz);
   const int n0 = nt * BN;
   const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -132,18 +148,22 @@ extern "C" int snx_decoder_splade_fwd_ex(const void* Hd, const void* W, const fl
   if (!Hd || !W || !bias || !cu_seqlens || !mask || !sparse || !keys || !token_weights || !scratch) return SNX_E_ARG;
   if (T <= 0 || nseq <= 0 || V <= 0 || K <= 0 || (K % 64) || max_seqlen > 65535) return SNX_E_SHAPE;
   const int n_tiles = cdiv(V, 128);
-  const int total = n_tiles * nseq;
+  const long total_l = 8L * cdiv(cdiv(nseq, SNX_DEC_GROUP), 8) * SNX_DEC_GROUP * n_tiles;
+  if (total_l > 0x7fffffffL) return SNX_E_SHAPE;
+  const int total = (int)total_l;
   unsigned short* rowpart = (unsigned short*)scratch;
   if (max_seqlen <= 64) {
     using Core = GemmCore<64, 128, 2, 2>;
     const size_t lds = Core::LDS_BYTES + (2 * 128 + 2 * 64) * 4;
     hipLaunchKernelGGL(decoder_splade_kernel<64>, dim3(total), dim3(256), lds, st, (const bf16_t*)Hd,
-                       (const bf16_t*)W, bias, cu_seqlens, mask, sparse, keys, rowpart, T, V, K, n_tiles, total);
+                       (const bf16_t*)W, bias, cu_seqlens, mask, sparse, keys, rowpart, T, V, K, n_tiles, total,
+                       nseq);
   } else {
     using Core = GemmCore<128, 128, 2, 2>;
     const size_t lds = Core::LDS_BYTES + (2 * 128 + 2 * 128) * 4;
     hipLaunchKernelGGL(decoder_splade_kernel<128>, dim3(total), dim3(256), lds, st, (const bf16_t*)Hd,
-                       (const bf16_t*)W, bias, cu_seqlens, mask, sparse, keys, rowpart, T, V, K, n_tiles, total);
+                       (const bf16_t*)W, bias, cu_seqlens, mask, sparse, keys, rowpart, T, V, K, n_tiles, total,
+                       nseq);
   }
   SNX_CHECK_LAUNCH();
   if (finalize) {

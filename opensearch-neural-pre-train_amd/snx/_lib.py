@@ -37,6 +37,8 @@ SIGNATURES = {
     "snx_geglu_bwd": (I32, [P, P, P, I32, I32, P]),
     "snx_attn_fwd": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_attn_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
+    "snx_attn_fwd_ex": (I32, [P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
+    "snx_attn_bwd_ex": (I32, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_gemm_nt_rope": (I32, [P, P, P, P, P, I32, I32, I32, I32, P]),
     "snx_gemm_nt_geglu_fwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "snx_gemm_nt_geglu_bwd": (I32, [P, P, P, P, I32, I32, I32, P]),
@@ -56,7 +58,7 @@ SIGNATURES = {
     "snx_weight_cache_bytes": (SZ, [P]),
     "snx_weight_cache_refresh": (I32, [P, P, P, P]),
     "snx_model_forward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P]),
-    "snx_model_backward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P]),
+    "snx_model_backward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P]),
     "snx_param_count": (I32, [P]),
     "snx_adamw_scratch_bytes": (SZ, []),
     "snx_adamw_clip_step": (I32, [P, P, P, P, I64, P, I64, I64, I64, P, P, P]),

@@ -249,7 +249,7 @@ class EncoderRuntime:
             tw_full = torch.zeros((T_pad,), dtype=torch.float32, device=dev)
             tw_full[scatter] = tw
             tw = tw_full
-        aux = (ids, mask, cu, pos, rg, rl, T, nseq, smax)
+        aux = (ids, mask, cu, pos, rg, rl, T, nseq, smax, groups)
         return sparse, tw, saved, aux
 
     def routing_rows(self, saved: torch.Tensor, aux) -> torch.Tensor:
@@ -261,7 +261,7 @@ class EncoderRuntime:
         return 0xFFFF - (keys & 0xFFFF)
 
     def backward_impl(self, saved: torch.Tensor, aux, g_sparse: torch.Tensor):
-        ids, mask, cu, pos, rg, rl, T, B, S = aux          # B = total sequences, S = longest
+        ids, mask, cu, pos, rg, rl, T, B, S, groups = aux  # B = total sequences, S = longest
         dev = self._device()
         if g_sparse.shape != (B, self.geom.vocab_size):
             raise ValueError("bad gradient shape")
@@ -281,7 +281,8 @@ class EncoderRuntime:
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         check(fn("snx_model_backward")(C.byref(self._desc), self._param_ptrs(), self._grad_ptrs(grads),
                                        _p(self._weights()), _p(ids), _p(mask), _p(cu), _p(pos), _p(rg), _p(rl),
-                                       _p(saved), _p(g), _p(scratch), T, B, S, _stream()), "snx_model_backward")
+                                       _p(saved), _p(g), _p(scratch), groups, T, B, S, _stream()),
+              "snx_model_backward")
         return ret
 
     def __call__(self, input_ids, attention_mask):

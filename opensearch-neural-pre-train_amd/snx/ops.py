@@ -257,8 +257,9 @@ def _check_seqs(cu: torch.Tensor, T: int, max_seqlen: int):
 
 
 def attn_fwd(qkv: torch.Tensor, cu: torch.Tensor, mask: torch.Tensor, max_seqlen: int, heads: int,
-             window: int, validate: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
-    """window < 0 -> global layer; else inclusive half-window."""
+             window: int, validate: bool = True, groups=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """window < 0 -> global layer; else inclusive half-window.  ``groups``: optional list of
+    (seq_begin, nseq, max_len) for consecutive sequence groups (launch sizing only)."""
     _chk(qkv, BF16, "qkv"); T = qkv.shape[0]
     if qkv.numel() != T * 3 * heads * 64:
         raise ValueError("attn_fwd: qkv must be [T, 3*heads*64]")
@@ -270,13 +271,20 @@ def attn_fwd(qkv: torch.Tensor, cu: torch.Tensor, mask: torch.Tensor, max_seqlen
     nseq = cu.numel() - 1
     out = torch.empty((T, heads * 64), dtype=BF16, device=qkv.device)
     lse = torch.empty((heads, T), dtype=torch.float32, device=qkv.device)
-    check(fn("snx_attn_fwd")(_p(qkv), _p(cu), _p(mask), _p(out), _p(lse), T, nseq, max_seqlen, heads, 64, window,
-                             _stream()), "snx_attn_fwd")
+    check(fn("snx_attn_fwd_ex")(_p(qkv), _p(cu), _p(mask), _p(out), _p(lse), _groups(groups), T, nseq, max_seqlen,
+                                heads, 64, window, _stream()), "snx_attn_fwd_ex")
     return out, lse
 
 
+def _groups(groups):
+    if groups is None:
+        return None
+    flat = [len(groups)] + [int(v) for g in groups for v in g]
+    return (C.c_int32 * len(flat))(*flat)
+
+
 def attn_bwd(qkv, out, dout, lse, cu, mask, max_seqlen: int, heads: int, window: int, validate: bool = True,
-             rope_table: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None):
+             rope_table: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None, groups=None):
     """Returns dqkv [T, 3*heads*64] bf16: gradients w.r.t. the post-RoPE q, k and v, or -- with
     rope_table/pos -- w.r.t. the pre-RoPE projections (inverse rotation fused into the epilogue)."""
     _chk(qkv, BF16, "qkv"); T = qkv.shape[0]
@@ -289,9 +297,9 @@ def attn_bwd(qkv, out, dout, lse, cu, mask, max_seqlen: int, heads: int, window:
     delta = torch.empty((heads, T), dtype=torch.float32, device=qkv.device)
     if rope_table is not None:
         _chk(rope_table, torch.float32, "rope_table"); _chk(pos, torch.int32, "pos", (T,))
-    check(fn("snx_attn_bwd")(_p(qkv), _p(out), _p(dout), _p(lse), _p(cu), _p(mask), _p(delta), _p(dqkv),
-                             _p(rope_table), _p(pos), T, nseq, max_seqlen, heads, 64, window, _stream()),
-          "snx_attn_bwd")
+    check(fn("snx_attn_bwd_ex")(_p(qkv), _p(out), _p(dout), _p(lse), _p(cu), _p(mask), _p(delta), _p(dqkv),
+                                _p(rope_table), _p(pos), _groups(groups), T, nseq, max_seqlen, heads, 64, window,
+                                _stream()), "snx_attn_bwd_ex")
     return dqkv
 
 

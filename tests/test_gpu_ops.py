@@ -461,3 +461,33 @@ def test_attention_bwd_fused_inverse_rope(dev):
     fused = ops.attn_bwd(qkv, out, dout, lse, cu, md, S, heads, 64, rope_table=tab, pos=pos)
     assert torch.equal(fused[:, 2 * heads * 64:], ref[:, 2 * heads * 64:])
     _ulp_close(fused, ref, "fused inverse rope", frac_exact=0.995)
+
+
+@pytest.mark.parametrize("window", [-1, 64])
+def test_attention_sequence_groups_only_size_the_launch(dev, window):
+    """Sequence groups (short queries + long documents in one token buffer) give every group the tile
+    count of its own max length and reorder the blocks; outputs must be bit-identical to the one-group
+    launch, and malformed group tables are refused before any launch."""
+    ops = _ops()
+    from snx._lib import SnxError
+    heads = 3
+    lens = [64] * 5 + [17, 33] + [256, 200, 129, 70] + [100] * 3
+    groups = [(0, 7, 64), (7, 4, 256), (11, 3, 100)]
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
+    T = int(cu[-1])
+    g = torch.Generator().manual_seed(43)
+    qkv = (torch.randn(T, 3 * heads * 64, generator=g) * 1.1).to(dev).to(BF16)
+    dout = (torch.randn(T, heads * 64, generator=g) * 0.5).to(dev).to(BF16)
+    mask = torch.ones(T, dtype=torch.int64, device=dev)
+    out0, lse0 = ops.attn_fwd(qkv, cu, mask, 256, heads, window)
+    out1, lse1 = ops.attn_fwd(qkv, cu, mask, 256, heads, window, groups=groups)
+    assert torch.equal(out0, out1) and torch.equal(lse0, lse1)
+    d0 = ops.attn_bwd(qkv, out0, dout, lse0, cu, mask, 256, heads, window)
+    d1 = ops.attn_bwd(qkv, out0, dout, lse0, cu, mask, 256, heads, window, groups=groups)
+    assert torch.equal(d0, d1)
+    for bad in ([(0, 7, 64), (8, 4, 256), (11, 3, 100)],      # gap
+                [(0, 7, 64), (7, 4, 256)],                      # does not cover all sequences
+                [(0, 14, 300)],                                 # max_len above max_seqlen
+                [(i, 1, 64) for i in range(9)]):                # too many groups
+        with pytest.raises(SnxError):
+            ops.attn_fwd(qkv, cu, mask, 256, heads, window, groups=bad)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Attention fwd/bwd timings on the fused query+document layout (64 x 64-token + 128 x 256-token sequences)."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "opensearch-neural-pre-train_amd"))
+import torch
+from snx import ops
+
+dev = torch.device("cuda:0")
+BF16 = torch.bfloat16
+
+
+def timeit(f, n=30, warm=5):
+    for _ in range(warm):
+        f()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        f()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+heads = 12
+for name, lens in [("fused q+p+n", [64] * 64 + [256] * 128), ("docs only", [256] * 128)]:
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
+    T = int(cu[-1])
+    mask = torch.ones(T, dtype=torch.int64, device=dev)
+    qkv = torch.randn(T, 3 * heads * 64, device=dev).to(BF16)
+    dout = torch.randn(T, heads * 64, device=dev).to(BF16)
+    grp = [(0, 64, 64), (64, 128, 256)] if len(lens) == 192 else None
+    for w in (-1, 64):
+        for gr in ([None, grp] if grp else [None]):
+            out, lse = ops.attn_fwd(qkv, cu, mask, 256, heads, w, validate=False, groups=gr)
+            f = timeit(lambda: ops.attn_fwd(qkv, cu, mask, 256, heads, w, validate=False, groups=gr))
+            b = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False, groups=gr))
+            print(f"{name} window={w} groups={'yes' if gr else 'no'}: fwd {f:.1f} us, bwd {b:.1f} us", flush=True)
+
+# queries alone: live blocks only (max_seqlen 64) vs 3 of 4 blocks exiting at once (max_seqlen 256)
+cu = (torch.arange(65, dtype=torch.int32) * 64).to(dev)
+T = 64 * 64
+mask = torch.ones(T, dtype=torch.int64, device=dev)
+qkv = torch.randn(T, 3 * heads * 64, device=dev).to(BF16)
+dout = torch.randn(T, heads * 64, device=dev).to(BF16)
+for ms in (64, 256):
+    out, lse = ops.attn_fwd(qkv, cu, mask, ms, heads, 64, validate=False)
+    f = timeit(lambda: ops.attn_fwd(qkv, cu, mask, ms, heads, 64, validate=False))
+    b = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, cu, mask, ms, heads, 64, validate=False))
+    print(f"queries only, max_seqlen={ms}: fwd {f:.1f} us, bwd {b:.1f} us", flush=True)
