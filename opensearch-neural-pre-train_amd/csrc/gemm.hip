@@ -50,11 +50,37 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
   for (int i = 0; i < Core::MI; ++i)
 #pragma unroll
     for (int j = 0; j < Core::NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int g4 = (lane >> 4) * 4;
   const int span0 = n0 + wn * 64;                    // first column of this wave's 64-column span
+  // Epilogue operands (residual stream / saved u) are requested BEFORE the K loop: each is a
+  // 64 KB read per tile that would otherwise start only after the last MFMA and leave the CU's
+  // other workgroup as the sole latency cover (RESID ran at 414, GEGLU_BWD at 268 TFLOP/s).
+  // 64 extra VGPRs are free: LDS already limits the CU to two 4-wave workgroups.
+  constexpr bool PRE = (EPI == EPI_RESID_F32 || EPI == EPI_GEGLU_BWD);
+  f32x4 pre[PRE ? Core::MI : 1][PRE ? Core::NI : 1];
+  if (PRE) {
+#pragma unroll
+    for (int i = 0; i < Core::MI; ++i) {
+      const int row = m0 + wm * Core::WTM + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < Core::NI; ++j) {
+        const int col = span0 + j * 16 + g4;
+        pre[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (row < M && col < N) {
+          if (EPI == EPI_RESID_F32) {
+            pre[i][j] = *(const f32x4*)(e.Hin + (long)row * N + col);
+          } else {
+            const long o = (long)row * (2 * N) + 64 * (col >> 5) + (col & 31);
+            const f32x2 a = *(const f32x2*)(e.U + o), g = *(const f32x2*)(e.U + o + 32);   // 4 bf16 each
+            pre[i][j] = (f32x4){a[0], a[1], g[0], g[1]};
+          }
+        }
+      }
+    }
+  }
+  Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
 #pragma unroll
   for (int i = 0; i < Core::MI; ++i) {
     const int row = m0 + wm * Core::WTM + i * 16 + (lane & 15);
@@ -68,7 +94,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
         if (EPI == EPI_STORE_BF16) {
           *(bf16x4*)(e.C + o) = pack4(acc[i][j]);
         } else {
-          const f32x4 h = *(const f32x4*)(e.Hin + o), v = acc[i][j];
+          const f32x4 h = pre[i][j], v = acc[i][j];
           *(f32x4*)(e.Hout + o) = (f32x4){h[0] + rbf(v[0]), h[1] + rbf(v[1]), h[2] + rbf(v[2]), h[3] + rbf(v[3])};
         }
       }
@@ -114,7 +140,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
         const int col = span0 + j * 16 + g4;          // natural column c of dy
         if (col >= N) continue;
         const long o = (long)row * (2 * N) + 64 * (col >> 5) + (col & 31);
-        const bf16x4 a4 = *(const bf16x4*)(e.U + o), gg4 = *(const bf16x4*)(e.U + o + 32);
+        const f32x2 ua = {pre[i][j][0], pre[i][j][1]}, ug = {pre[i][j][2], pre[i][j][3]};
+        const bf16x4 a4 = __builtin_bit_cast(bf16x4, ua), gg4 = __builtin_bit_cast(bf16x4, ug);
         bf16x4 da, dg;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

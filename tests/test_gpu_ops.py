@@ -491,3 +491,34 @@ def test_attention_sequence_groups_only_size_the_launch(dev, window):
                 [(i, 1, 64) for i in range(9)]):                # too many groups
         with pytest.raises(SnxError):
             ops.attn_fwd(qkv, cu, mask, 256, heads, window, groups=bad)
+
+
+def test_gelu_exhaustive_over_bf16_inputs(dev):
+    """GELU inputs are bf16 (Linear outputs under autocast), so the device's erfc-form GELU can be checked
+    on ALL of them: bf16(gelu(x)) must equal torch's fp32 exact-erf GELU rounded to bf16 for every
+    finite x > -3.14 (below that torch's own 1+erf cancellation decides the last bits: compared
+    against the float64 value instead), and the derivative must be within fp32 noise of float64."""
+    ops = _ops()
+    bits = torch.arange(65536, dtype=torch.int32)
+    a = (bits << 16).view(torch.float32)
+    keep = torch.isfinite(a) & ((a.abs() > 1e-30) | (a == 0)) & (a.abs() < 1e30)
+    a = a[keep]
+    n = (a.numel() // 128) * 128
+    a = a[:n].view(-1, 128)
+    u = torch.cat([a, torch.ones_like(a)], dim=1).to(BF16).to(dev)
+    y = ops.geglu_fwd(u).float().cpu()
+    ref32 = torch.nn.functional.gelu(a).to(BF16).float()
+    ref64 = (a.double() * 0.5 * torch.erfc(-a.double() / 2 ** 0.5))
+    main = a > -3.14
+    assert torch.equal(y[main], ref32[main])
+    tail = ~main
+    assert torch.allclose(y[tail].double(), ref64[tail], rtol=2 ** -8, atol=1e-7)    # torch fp32 itself: ~3e-7 here
+    # derivative: dy = 1, g = 1 -> da = bf16(gelu'(a))
+    du = ops.geglu_bwd(u, torch.ones_like(a).to(BF16).to(dev)).float().cpu()
+    x = a.double()
+    grad64 = 0.5 * torch.erfc(-x / 2 ** 0.5) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    got = du[:, :128].double()
+    assert torch.allclose(got, grad64, rtol=2 ** -8, atol=4e-7)
+    exact = (got == grad64.float().to(BF16).double()).double().mean()
+    assert exact > 0.995, exact
+    assert torch.equal(du[:, 128:], y)                # dg = dy * bf16(gelu(a))
