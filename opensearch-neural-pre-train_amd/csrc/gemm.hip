@@ -36,12 +36,41 @@ struct EpiArgs {
 
 __device__ __forceinline__ bf16x4 pack4(const f32x4 v) { return (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; }
 
+// ---- coalesced epilogue -----------------------------------------------------------------------
+// In the (transposed) accumulator layout the 16 lanes li = 0..15 of a store instruction are 16
+// different ROWS, so a direct store is 64 separate 8-byte transactions per instruction and the
+// texture addresser, not HBM, sets the epilogue time (measured on the 256x256 kernel: 786 TFLOP/s
+// with such stores, 1047 without, no change when all stores hit one L2-resident region).  Each
+// wave therefore bounces its 64x64 bf16 result through a PRIVATE 8 KiB of the (finished) operand
+// LDS and writes it back row-major, 16 B per lane, 8 lanes per 128-byte line.
+// Staging image: 64 rows x 128 B; 16-B chunk c of row r sits at chunk c ^ (r & 7) and its two
+// 8-B halves are swapped when bit 3 of r is set -- ds_write_b64 from the accumulator layout and
+// ds_read_b128 in the row-major layout are both bank-conflict free.
+__device__ __forceinline__ void stg_put(char* w, int row, int col, bf16x4 v) {        // col % 4 == 0
+  *(bf16x4*)(w + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + ((((col >> 2) ^ (row >> 3)) & 1) << 3)) = v;
+}
+template <bool SWAP>
+__device__ __forceinline__ bf16x8 stg_get(const char* w, int row, int chunk) {
+  const bf16x8 v = *(const bf16x8*)(w + row * 128 + (((chunk ^ row) & 7) << 4));
+  if (!SWAP) return v;
+  return (bf16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+}
+// second staging image for a 64 x 32 result (GeGLU's y): rows of 64 B
+__device__ __forceinline__ void stg32_put(char* w, int row, int col, bf16x4 v) {
+  *(bf16x4*)(w + row * 64 + ((((col >> 3) ^ (row >> 1)) & 3) << 4) + ((((col >> 2) ^ (row >> 3)) & 1) << 3)) = v;
+}
+__device__ __forceinline__ bf16x8 stg32_get(const char* w, int row, int chunk) {
+  const bf16x8 v = *(const bf16x8*)(w + row * 64 + (((chunk ^ (row >> 1)) & 3) << 4));
+  return ((row >> 3) & 1) ? (bf16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]} : v;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N, int K, int tiles_n, int ntiles,
     EpiArgs e) {
   using Core = GemmCore<BM, BN, WAVES_M, WAVES_N>;
-  static_assert(Core::WTN == 64, "fused epilogues pair the four 16-column tiles of a 64-column wave span");
+  static_assert(Core::WTN == 64 && Core::WTM == 64, "epilogues assume a 64x64 wave tile");
+  static_assert(Core::LDS_BYTES >= WAVES_M * WAVES_N * 16384, "16 KiB of staging per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
@@ -52,105 +81,152 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
     for (int j = 0; j < Core::NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int g4 = (lane >> 4) * 4;
-  const int span0 = n0 + wn * 64;                    // first column of this wave's 64-column span
-  // Epilogue operands (residual stream / saved u) are requested BEFORE the K loop: each is a
-  // 64 KB read per tile that would otherwise start only after the last MFMA and leave the CU's
-  // other workgroup as the sole latency cover (RESID ran at 414, GEGLU_BWD at 268 TFLOP/s).
-  // 64 extra VGPRs are free: LDS already limits the CU to two 4-wave workgroups.
-  constexpr bool PRE = (EPI == EPI_RESID_F32 || EPI == EPI_GEGLU_BWD);
-  f32x4 pre[PRE ? Core::MI : 1][PRE ? Core::NI : 1];
-  if (PRE) {
+  const int li = lane & 15, g4 = (lane >> 4) * 4;
+  const int row0 = m0 + wm * 64;                     // first row / column of this wave's 64x64 tile
+  const int span0 = n0 + wn * 64;
+  // row-major role of this lane in the write-back: rows (lane >> 3) + 8k, 8 columns from 8 * (lane & 7)
+  const int rr = lane >> 3, rc = lane & 7;
+  const bool wide = (N & 7) == 0;                    // 16-B row-major stores need N % 8 == 0 (else: direct stores)
+
+  // Epilogue operands (residual stream / saved u) are requested BEFORE the K loop, already in the
+  // row-major layout: each is a 64 KB read per tile that would otherwise start only after the last
+  // MFMA.  64 extra VGPRs are free: LDS already limits the CU to two 4-wave workgroups.
+  constexpr bool PRE = (EPI == EPI_RESID_F32 || EPI == EPI_GEGLU_BWD || EPI == EPI_ROPE);
+  f32x4 pre[PRE ? 8 : 1][2];
+  const bool rotate = EPI == EPI_ROPE && span0 < N && span0 < e.rope_cols;   // wave-uniform: a head of q or k
+  if (EPI == EPI_ROPE) {
+    // (cos, sin) of this lane's 4 rows x 8 rotation pairs, in the accumulator layout: the dependent
+    // pos -> table loads would otherwise sit at the end of the tile with nothing to hide behind
+    if (rotate) {
 #pragma unroll
-    for (int i = 0; i < Core::MI; ++i) {
-      const int row = m0 + wm * Core::WTM + i * 16 + (lane & 15);
+      for (int i = 0; i < Core::MI; ++i) {
+        const int row = row0 + i * 16 + li;
+        const f32x4* cs = (const f32x4*)(e.rope_tab + (long)e.pos[row < M ? row : M - 1] * 32 + g4);
 #pragma unroll
-      for (int j = 0; j < Core::NI; ++j) {
-        const int col = span0 + j * 16 + g4;
-        pre[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (row < M && col < N) {
-          if (EPI == EPI_RESID_F32) {
-            pre[i][j] = *(const f32x4*)(e.Hin + (long)row * N + col);
-          } else {
-            const long o = (long)row * (2 * N) + 64 * (col >> 5) + (col & 31);
-            const f32x2 a = *(const f32x2*)(e.U + o), g = *(const f32x2*)(e.U + o + 32);   // 4 bf16 each
-            pre[i][j] = (f32x4){a[0], a[1], g[0], g[1]};
-          }
+        for (int j = 0; j < 2; ++j) {
+          pre[i * 2 + j][0] = cs[j * 8];             // pairs j*16 + g4 + {0, 1}
+          pre[i * 2 + j][1] = cs[j * 8 + 1];         // pairs j*16 + g4 + {2, 3}
+        }
+      }
+    }
+  } else if (PRE && wide) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = row0 + rr + 8 * k, col = span0 + rc * 8;
+      pre[k][0] = pre[k][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (row < M && col < N) {
+        if (EPI == EPI_RESID_F32) {
+          const float* h = e.Hin + (long)row * N + col;
+          pre[k][0] = *(const f32x4*)h;
+          pre[k][1] = *(const f32x4*)(h + 4);
+        } else {                                     // dy columns [col, col+8) <-> a at u[64q + 8s], g at +32
+          const bf16_t* u = e.U + (long)row * (2 * N) + 64 * (col >> 5) + (col & 31);
+          pre[k][0] = *(const f32x4*)u;              // 8 bf16 of a
+          pre[k][1] = *(const f32x4*)(u + 32);       // 8 bf16 of g
         }
       }
     }
   }
   Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
-#pragma unroll
-  for (int i = 0; i < Core::MI; ++i) {
-    const int row = m0 + wm * Core::WTM + i * 16 + (lane & 15);
-    if (row >= M) continue;
+
+  if (!wide) {                                       // odd widths (tests, tiny heads): direct 8-byte stores
     if (EPI == EPI_STORE_BF16 || EPI == EPI_RESID_F32) {
 #pragma unroll
-      for (int j = 0; j < Core::NI; ++j) {
-        const int col = span0 + j * 16 + g4;
-        if (col >= N) continue;                       // N % 4 == 0: the 4 columns are in or out together
-        const long o = (long)row * N + col;
-        if (EPI == EPI_STORE_BF16) {
-          *(bf16x4*)(e.C + o) = pack4(acc[i][j]);
-        } else {
-          const f32x4 h = pre[i][j], v = acc[i][j];
-          *(f32x4*)(e.Hout + o) = (f32x4){h[0] + rbf(v[0]), h[1] + rbf(v[1]), h[2] + rbf(v[2]), h[3] + rbf(v[3])};
+      for (int i = 0; i < Core::MI; ++i) {
+        const int row = row0 + i * 16 + li;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < Core::NI; ++j) {
+          const int col = span0 + j * 16 + g4;
+          if (col >= N) continue;                     // N % 4 == 0: the 4 columns are in or out together
+          const long o = (long)row * N + col;
+          if (EPI == EPI_STORE_BF16) {
+            *(bf16x4*)(e.C + o) = pack4(acc[i][j]);
+          } else {
+            const f32x4 h = *(const f32x4*)(e.Hin + o), v = acc[i][j];
+            *(f32x4*)(e.Hout + o) = (f32x4){h[0] + rbf(v[0]), h[1] + rbf(v[1]), h[2] + rbf(v[2]), h[3] + rbf(v[3])};
+          }
         }
       }
-    } else if (EPI == EPI_ROPE) {
-      if (span0 >= N) continue;                       // N % 64 == 0
-      bf16_t* crow = e.C + (long)row * N + span0 + g4;
-      if (span0 < e.rope_cols) {                      // one head of q or k: rotate pairs (d, d+32)
-        const f32x2* cs = e.rope_tab + (long)e.pos[row] * 32 + g4;
+    }
+    return;                                          // the fused variants require N % 64 == 0 (launch_nt)
+  }
+
+  __syncthreads();                                   // every wave is done reading the operand tiles
+  char* w = smem + wave * 16384;
+  char* w2 = w + 8192;
+  // ---- accumulator layout -> staging image(s) (all lane-local math happens here) ----
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x4 lo, hi;
+  for (int i = 0; i < Core::MI; ++i) {
+    const int lrow = i * 16 + li, row = row0 + lrow;
+    if (EPI == EPI_ROPE && rotate) {                 // rotate pairs (d, d+32)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const f32x2 t = cs[j * 16 + r];
-            const float x1 = rbf(acc[i][j][r]), x2 = rbf(acc[i][j + 2][r]);   // Linear output is bf16
-            lo[r] = x1 * t[0] - x2 * t[1];
-            hi[r] = x2 * t[0] + x1 * t[1];
-          }
-          *(bf16x4*)(crow + j * 16) = pack4(lo);
-          *(bf16x4*)(crow + (j + 2) * 16) = pack4(hi);
+      for (int j = 0; j < 2; ++j) {
+        f32x4 lo, hi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float c = pre[i * 2 + j][r >> 1][(r & 1) * 2], sn = pre[i * 2 + j][r >> 1][(r & 1) * 2 + 1];
+          const float x1 = rbf(acc[i][j][r]), x2 = rbf(acc[i][j + 2][r]);   // Linear output is bf16
+          lo[r] = x1 * c - x2 * sn;
+          hi[r] = x2 * c + x1 * sn;
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *(bf16x4*)(crow + j * 16) = pack4(acc[i][j]);
+        stg_put(w, lrow, j * 16 + g4, pack4(lo));
+        stg_put(w, lrow, (j + 2) * 16 + g4, pack4(hi));
       }
     } else if (EPI == EPI_GEGLU_FWD) {
-      if (span0 >= N) continue;                       // N % 64 == 0
-      bf16_t* urow = e.C + (long)row * N + span0 + g4;
-      bf16_t* yrow = e.Y + (long)row * (N / 2) + (span0 / 2) + g4;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const bf16x4 a4 = pack4(acc[i][j]), gg4 = pack4(acc[i][j + 2]);
-        *(bf16x4*)(urow + j * 16) = a4;
-        *(bf16x4*)(urow + (j + 2) * 16) = gg4;
+        stg_put(w, lrow, j * 16 + g4, a4);
+        stg_put(w, lrow, (j + 2) * 16 + g4, gg4);
         bf16x4 y4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) y4[r] = f2bf(rbf(gelu_f(bf2f(a4[r]))) * bf2f(gg4[r]));
-        *(bf16x4*)(yrow + j * 16) = y4;
+        stg32_put(w2, lrow, j * 16 + g4, y4);
       }
-    } else {                                          // EPI_GEGLU_BWD: this GEMM's output is dy [M, N = I]
+    } else {
 #pragma unroll
-      for (int j = 0; j < Core::NI; ++j) {
-        const int col = span0 + j * 16 + g4;          // natural column c of dy
-        if (col >= N) continue;
-        const long o = (long)row * (2 * N) + 64 * (col >> 5) + (col & 31);
-        const f32x2 ua = {pre[i][j][0], pre[i][j][1]}, ug = {pre[i][j][2], pre[i][j][3]};
-        const bf16x4 a4 = __builtin_bit_cast(bf16x4, ua), gg4 = __builtin_bit_cast(bf16x4, ug);
-        bf16x4 da, dg;
+      for (int j = 0; j < Core::NI; ++j) stg_put(w, lrow, j * 16 + g4, pack4(acc[i][j]));
+    }
+  }
+  // ---- staging image -> global, row-major ----
+  const int col = span0 + rc * 8;
+  if (col < N) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float af = bf2f(a4[r]), gf = bf2f(gg4[r]), df = rbf(acc[i][j][r]);
+    for (int k = 0; k < 8; ++k) {
+      const int lrow = rr + 8 * k, row = row0 + lrow;
+      const bf16x8 v = (k & 1) ? stg_get<true>(w, lrow, rc) : stg_get<false>(w, lrow, rc);
+      if (row >= M) continue;
+      if (EPI == EPI_STORE_BF16 || EPI == EPI_ROPE || EPI == EPI_GEGLU_FWD) {
+        *(bf16x8*)(e.C + (long)row * N + col) = v;
+      } else if (EPI == EPI_RESID_F32) {
+        const f32x4 h0 = pre[k][0], h1 = pre[k][1];
+        float* o = e.Hout + (long)row * N + col;
+        *(f32x4*)o = (f32x4){h0[0] + bf2f(v[0]), h0[1] + bf2f(v[1]), h0[2] + bf2f(v[2]), h0[3] + bf2f(v[3])};
+        *(f32x4*)(o + 4) = (f32x4){h1[0] + bf2f(v[4]), h1[1] + bf2f(v[5]), h1[2] + bf2f(v[6]), h1[3] + bf2f(v[7])};
+      } else {                                       // EPI_GEGLU_BWD: v = dy (bf16); du = GeGLU'(u, dy)
+        const bf16x8 a8 = __builtin_bit_cast(bf16x8, pre[k][0]), g8 = __builtin_bit_cast(bf16x8, pre[k][1]);
+        bf16x8 da, dg;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float af = bf2f(a8[r]), gf = bf2f(g8[r]), df = bf2f(v[r]);
           dg[r] = f2bf(df * rbf(gelu_f(af)));
           da[r] = f2bf(rbf(df * gf) * gelu_grad_f(af));
         }
-        *(bf16x4*)(e.C + o) = da;
-        *(bf16x4*)(e.C + o + 32) = dg;
+        bf16_t* o = e.C + (long)row * (2 * N) + 64 * (col >> 5) + (col & 31);
+        *(bf16x8*)o = da;
+        *(bf16x8*)(o + 32) = dg;
+      }
+    }
+  }
+  if (EPI == EPI_GEGLU_FWD) {                        // y [M, N/2]: 64 x 32 per wave, rows (lane >> 2) + 16k
+    const int ycol = (span0 >> 1) + (lane & 3) * 8;
+    if (span0 < N) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int lrow = (lane >> 2) + 16 * k, row = row0 + lrow;
+        const bf16x8 v = stg32_get(w2, lrow, lane & 3);
+        if (row < M) *(bf16x8*)(e.Y + (long)row * (N >> 1) + ycol) = v;
       }
     }
   }

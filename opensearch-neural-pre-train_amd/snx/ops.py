@@ -100,12 +100,14 @@ def gemm_tn_accum(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor) -> None:
     check(fn("snx_gemm_tn_accum")(_p(dy), _p(x), _p(dw), M, N, K, _stream()), "snx_gemm_tn_accum")
 
 
-def gemm_nt_rope(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, rope_cols: int):
-    """qkv = rope(A @ B^T) on columns < rope_cols (fused Wqkv + apply_rotary_pos_emb)."""
+def gemm_nt_rope(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, rope_cols: int,
+                 validate: bool = True):
+    """qkv = rope(A @ B^T) on columns < rope_cols (fused Wqkv + apply_rotary_pos_emb).
+    ``validate`` checks pos against the table length (a device sync: off in timing loops)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b")
     M, K = a.shape; N = b.shape[0]
     _chk(table, torch.float32, "table"); _chk(pos, torch.int32, "pos", (M,))
-    if b.shape[1] != K or K % 64 or N % 64 or int(pos.max()) >= table.shape[0]:
+    if b.shape[1] != K or K % 64 or N % 64 or (validate and int(pos.max()) >= table.shape[0]):
         raise ValueError("gemm_nt_rope: bad shapes")
     c = torch.empty((M, N), dtype=BF16, device=a.device)
     check(fn("snx_gemm_nt_rope")(_p(a), _p(b), _p(c), _p(table), _p(pos), rope_cols, M, N, K, _stream()),

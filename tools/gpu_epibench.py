@@ -41,10 +41,13 @@ report("resid  N=768 K=768", timeit(lambda: ops.gemm_nt_resid(x, w, hin)), 2.0 *
 y = rnd(M, I); wo = rnd(H, I, scale=0.05)
 report("resid  N=768 K=1152", timeit(lambda: ops.gemm_nt_resid(y, wo, hin)), 2.0 * M * H * I)
 wqkv = rnd(3 * H, H, scale=0.05)
+report("store  N=2304 K=768", timeit(lambda: ops.gemm_nt(x, wqkv)), 2.0 * M * 3 * H * H)
+report("torch  N=2304 K=768", timeit(lambda: torch.matmul(x, wqkv.t())), 2.0 * M * 3 * H * H)
 tab = ops.rope_table(256, 64, 160000.0, dev)
 pos = torch.arange(256, dtype=torch.int32, device=dev).repeat(M // 256)
-report("rope   N=2304 K=768", timeit(lambda: ops.gemm_nt_rope(x, wqkv, tab, pos, 2 * H)), 2.0 * M * 3 * H * H)
+report("rope   N=2304 K=768", timeit(lambda: ops.gemm_nt_rope(x, wqkv, tab, pos, 2 * H, validate=False)), 2.0 * M * 3 * H * H)
 wi = rnd(2 * I, H, scale=0.05)
 report("geglu_fwd N=2304 K=768", timeit(lambda: ops.gemm_nt_geglu_fwd(x, wi)), 2.0 * M * 2 * I * H)
 u = rnd(M, 2 * I); wot = rnd(I, H, scale=0.05)
+report("store  N=1152 K=768", timeit(lambda: ops.gemm_nt(x, wot)), 2.0 * M * I * H)
 report("geglu_bwd N=1152 K=768", timeit(lambda: ops.gemm_nt_geglu_bwd(x, wot, u)), 2.0 * M * I * H)
