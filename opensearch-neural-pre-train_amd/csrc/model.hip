@@ -109,7 +109,9 @@ struct BwdPlan {
   size_t dh;        // fp32 [T,H]   gradient of the residual stream
   size_t a, b;      // bf16 [T,H]
   size_t c;         // bf16 [T,I]
-  size_t w;         // bf16 [T,max(3H,2I)]
+  size_t w;         // bf16 [T,max(3H,2I)]   du (GeGLU backward output)
+  size_t w2;        // bf16 [T,3H]           dqkv: its own buffer, so that the dW GEMM that still reads du on the
+                    //                       side stream never holds back the attention backward
   size_t delta;     // fp32 [heads,T]
   size_t splade;    // bucket lists of the routed SPLADE backward
   size_t total;
@@ -123,6 +125,7 @@ void plan_bwd(const snx_model_desc* d, long T, long nseq, long max_seqlen, BwdPl
   p.a = take(T * H * 2); p.b = take(T * H * 2);
   p.c = take(T * I * 2);
   p.w = take(T * (3 * H > 2 * I ? 3 * H : 2 * I) * 2);
+  p.w2 = take(T * 3 * H * 2);
   p.delta = take((size_t)d->heads * T * 4);
   p.splade = take(snx_splade_bwd_scratch_bytes((int)nseq, (int)max_seqlen, d->vocab));
   p.total = off;
@@ -171,6 +174,36 @@ struct ProfScope {
   ~ProfScope() { if (live) { hipEventRecord(r.b, st); g_prof.recs.push_back(r); } }
 };
 #define PROF(cls, work) ProfScope prof_scope__(cls, (double)(work), st)
+
+// ---- side stream for the weight-gradient GEMMs ------------------------------------------------
+// dW = dY^T X needs nothing from the dX chain after its operands exist, and is MFMA-bound while
+// the LayerNorm / attention backward kernels beside it are HBM- and VALU-bound; it also fills the
+// last, partly empty round of workgroups of the dX GEMMs.  The backward therefore forks every dW
+// GEMM onto one internal stream (events both ways guard the three scratch buffers it reads) and
+// joins before returning, so callers still see everything ordered on THEIR stream.
+// One process drives one GPU, hence one side stream per process.
+struct Side {
+  hipStream_t s = nullptr;
+  std::vector<hipEvent_t> ev;
+  size_t next = 0;
+  int enabled = -1;
+  bool on() {
+    if (enabled < 0) {
+      const char* e = getenv("SNX_BWD_OVERLAP");
+      enabled = (e && e[0] == '0') ? 0 : 1;
+      if (enabled && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) enabled = 0;
+    }
+    return enabled == 1;
+  }
+  hipEvent_t get() {
+    if (next == ev.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      ev.push_back(e);
+    }
+    return ev[next++];
+  }
+} g_side;
 
 #define RC(call)            \
   do {                      \
@@ -317,8 +350,29 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
   auto G = [&](int idx) { return (float*)grads[idx]; };
   auto hbuf = [&](int i) { return (const float*)(sv + s.h[i]); };
   float* dh = (float*)(sc + b.dh);
-  char *A = sc + b.a, *Bb = sc + b.b, *Wd = sc + b.w;
+  char *A = sc + b.a, *Bb = sc + b.b, *Wd = sc + b.w, *Wq = sc + b.w2;
   const long n4 = (long)T * H / 4;
+
+  // dW GEMMs go to the side stream unless the per-class profiler is timing kernels one by one
+  const bool overlap = !g_prof.on && g_side.on();
+  hipStream_t ss = overlap ? g_side.s : st;
+  g_side.next = 0;
+  auto fork = [&]() -> int {                          // side stream: wait for everything enqueued on st so far
+    if (!overlap) return SNX_OK;
+    hipEvent_t e = g_side.get();
+    if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(ss, e, 0) != hipSuccess) return SNX_E_ARG;
+    return SNX_OK;
+  };
+  auto mark = [&](hipEvent_t& e) -> int {             // e = "side stream has finished what it was given so far"
+    if (!overlap) return SNX_OK;
+    e = g_side.get();
+    return (e && hipEventRecord(e, ss) == hipSuccess) ? SNX_OK : SNX_E_ARG;
+  };
+  auto join = [&](hipEvent_t e) -> int {              // st: wait for that point of the side stream
+    if (!overlap || !e) return SNX_OK;
+    return hipStreamWaitEvent(st, e, 0) == hipSuccess ? SNX_OK : SNX_E_ARG;
+  };
+  hipEvent_t read_a = nullptr, read_du = nullptr, read_dqkv = nullptr;   // last side-stream reader of A / Wd / Wq
 
   const double TH = (double)T * H;
   // SPLADE tail + decoder (sparse routed), head
@@ -335,21 +389,33 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
     const bool global = (l % d->global_every) == 0;
     const double attn_keys = global ? max_seqlen : (2 * d->window + 1 < max_seqlen ? 2 * d->window + 1 : max_seqlen);
     // ---- MLP:  h[2l+2] = h[2l+1] + Wo( gelu(a) * g ),  [a|g] = Wi( LN(h[2l+1]) )
-    { PROF(PC_GEMM_TN, 2.0 * TH * I); RC(snx_gemm_tn_accum(A, sv + s.y[l], G(p.wo_mlp(l)), T, H, I, st)); }
+    RC(fork());
+    { ProfScope ps(PC_GEMM_TN, 2.0 * TH * I, ss); RC(snx_gemm_tn_accum(A, sv + s.y[l], G(p.wo_mlp(l)), T, H, I, ss)); }
+    RC(mark(read_a));
+    RC(join(read_du));                             // previous layer's dWi has finished reading du
     { PROF(PC_GEMM_NT, 2.0 * TH * I);             // dy = dh Wo, GeGLU backward fused -> du [T,2I] (interleaved)
       RC(snx_gemm_nt_geglu_bwd(A, wc + c.wom_t[l], sv + s.u[l], Wd, T, I, H, st)); }
-    { PROF(PC_GEMM_TN, 2.0 * TH * 2 * I); RC(snx_gemm_tn_accum_interleaved(Wd, sv + s.x_mlp[l], G(p.wi(l)), T, 2 * I, H, st)); }
+    RC(fork());
+    { ProfScope ps(PC_GEMM_TN, 2.0 * TH * 2 * I, ss); RC(snx_gemm_tn_accum_interleaved(Wd, sv + s.x_mlp[l], G(p.wi(l)), T, 2 * I, H, ss)); }
+    RC(mark(read_du));
+    RC(join(read_a));                              // dWo(mlp) has finished reading A
     { PROF(PC_GEMM_NT, 2.0 * TH * 2 * I); RC(snx_gemm_nt_bf16(Wd, wc + c.wi_t[l], A, T, H, 2 * I, st)); }   // dx [T,H]
     { PROF(PC_LN_BWD, TH * 16); RC(snx_ln_bwd(A, hbuf(2 * l + 1), F(p.mlp_norm(l)), dh, A, G(p.mlp_norm(l)), T, H, d->ln_eps, 0, st)); }
     // ---- attention:  h[2l+1] = h[2l] + Wo( attn( rope( Wqkv( LN(h[2l]) ) ) ) )
-    { PROF(PC_GEMM_TN, 2.0 * TH * H); RC(snx_gemm_tn_accum(A, sv + s.attn[l], G(p.wo(l)), T, H, H, st)); }
+    RC(fork());
+    { ProfScope ps(PC_GEMM_TN, 2.0 * TH * H, ss); RC(snx_gemm_tn_accum(A, sv + s.attn[l], G(p.wo(l)), T, H, H, ss)); }
+    RC(mark(read_a));
     { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(A, wc + c.wo_t[l], Bb, T, H, H, st)); }    // d(attn out)
+    RC(join(read_dqkv));                           // previous layer's dWqkv has finished reading dqkv
     { PROF(PC_ATTN_BWD, 10.0 * TH * attn_keys);
       RC(snx_attn_bwd_ex(sv + s.qkv[l], sv + s.attn[l], Bb, (const float*)(sv + s.lse[l]), cu_seqlens, mask,
-                         (float*)(sc + b.delta), Wd, global ? rope_global : rope_local, pos, groups, T, nseq,
+                         (float*)(sc + b.delta), Wq, global ? rope_global : rope_local, pos, groups, T, nseq,
                          max_seqlen, d->heads, d->head_dim, global ? -1 : d->window, st)); }      // inverse RoPE fused
-    { PROF(PC_GEMM_TN, 2.0 * TH * 3 * H); RC(snx_gemm_tn_accum(Wd, sv + s.x_attn[l], G(p.wqkv(l)), T, 3 * H, H, st)); }
-    { PROF(PC_GEMM_NT, 2.0 * TH * 3 * H); RC(snx_gemm_nt_bf16(Wd, wc + c.wqkv_t[l], A, T, H, 3 * H, st)); }   // dx [T,H]
+    RC(fork());
+    { ProfScope ps(PC_GEMM_TN, 2.0 * TH * 3 * H, ss); RC(snx_gemm_tn_accum(Wq, sv + s.x_attn[l], G(p.wqkv(l)), T, 3 * H, H, ss)); }
+    RC(mark(read_dqkv));
+    RC(join(read_a));                              // dWo(attn) has finished reading A
+    { PROF(PC_GEMM_NT, 2.0 * TH * 3 * H); RC(snx_gemm_nt_bf16(Wq, wc + c.wqkv_t[l], A, T, H, 3 * H, st)); }   // dx [T,H]
     if (l > 0) {
       PROF(PC_LN_BWD, TH * 16);
       RC(snx_ln_bwd(A, hbuf(2 * l), F(p.attn_norm(l)), dh, A, G(p.attn_norm(l)), T, H, d->ln_eps, 0, st));
@@ -359,6 +425,7 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
       SNX_CHECK_LAUNCH();
     }
   }
+  RC(join(read_dqkv));                             // the side stream is in order: its last mark covers all of it
   { PROF(PC_EMBED, TH * 12);
     RC(snx_embed_ln_bwd(dh, ids, F(p.tok_emb()), F(p.emb_norm()), G(p.tok_emb()), G(p.emb_norm()), T, H, d->ln_eps,
                         d->pad_id, st)); }
