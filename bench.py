@@ -96,11 +96,40 @@ def cpu_baseline(seconds_budget: float = 30.0):
                       "clip+AdamW every step"}
 
 
+# kernel names (as rocprofv3 reports them) behind each profiler class, for the PMC traffic lookup
+PMC_KERNELS = {
+    "gemm_nt_bf16": ["gemm_nt_kernel<128, 128, 2, 2, 0>", "gemm_nt_kernel<128, 128, 2, 2, 2>",
+                     "gemm_nt_kernel<128, 128, 2, 2, 3>", "gemm_nt_kernel<128, 128, 2, 2, 4>"],
+    "gemm_nt_resid": ["gemm_nt_kernel<128, 128, 2, 2, 1>"],
+    "gemm_tn_accum": ["gemm_tn_kernel"],
+    "decoder_splade_fwd": ["decoder_splade_kernel"],
+    "attn_fwd": ["attn_fwd_kernel"],
+    "attn_bwd": ["attn_bwd_dq_kernel", "attn_bwd_dk"],
+}
+
+
+def pmc_traffic(cls: str):
+    """Average fabric bytes per launch of the class's kernels, from the committed counter passes
+    (tools/pmc_traffic.py); None when the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            kernels = json.load(fh)["kernels"]
+    except (OSError, KeyError, ValueError):
+        return None
+    tot = n = 0.0
+    for name, rec in kernels.items():
+        if any(name.startswith(k) for k in PMC_KERNELS.get(cls, [])):
+            tot += rec["fabric_bytes_per_launch"] * rec["launches"]
+            n += rec["launches"]
+    return tot / n if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--q-len", type=int, default=64)
     ap.add_argument("--d-len", type=int, default=256)
@@ -214,10 +243,14 @@ def main():
         dom = max((c for c in classes if c in mfma), key=lambda c: classes[c]["ms_per_step"])
         ach = classes[dom]["work_per_s"] / 1e12
         result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-                              "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                              "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom),
                               "avg_launch_us": classes[dom]["avg_us"],
                               "note": "algorithmic FLOPs of every launch of this kernel class in a step / summed "
-                                      "HIP-event durations of those launches (rank 0, profiled extra steps)"}
+                                      "HIP-event durations of those launches (rank 0; accum extra steps right after "
+                                      "the timed region, with the backward's side stream folded into the launch "
+                                      "stream so that kernels are timed one at a time); traffic = fabric bytes per "
+                                      "launch from the committed PMC passes (profiles/r01_pmc_traffic.json: "
+                                      "2 x FETCH_SIZE + WRITE_SIZE, averaged over this class's kernels)"}
         result["kernel_classes"] = classes
     elif world > 1 and not args.no_profile:
         for _ in range(args.accum):     # keep collectives matched with rank 0's profiled steps
