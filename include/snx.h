@@ -95,6 +95,14 @@ int snx_model_backward(const snx_model_desc* d, const void* const* params /*[hos
                        const float* g_sparse, void* scratch, const int32_t* groups /*[host] or NULL, as forward*/,
                        int32_t T, int32_t nseq, int32_t max_seqlen, hipStream_t stream);
 
+/* ---- inference post-processing (ref:benchmark/encoders.py:309-345 NeuralSparseEncoderV33._encode_batch) ---- */
+/* Per row of rep [B,V] fp32: entries with rep > 0 and allowed[v] != 0 survive.  k > 0 and more than k survivors:
+ * the k largest, weight descending, ties lowest id first (out_sorted[b] = 1); otherwise all survivors in id
+ * order (out_sorted[b] = 0).  out_val / out_idx [B,cap] (cap >= min(k,V), or >= V when k <= 0), out_cnt [B].
+ * k <= 16384. */
+int snx_sparse_topk(const float* rep, const uint8_t* allowed, float* out_val, int32_t* out_idx, int32_t* out_cnt,
+                    int32_t* out_sorted, int32_t B, int32_t V, int32_t k, int32_t cap, hipStream_t stream);
+
 /* ---- SPLADELossV33 (ref:src/model/losses.py:183-297) ------------------------------------- */
 /* dims [host] = {B, Bp, k, V, label_off, bf16_mm}: q [B,V], p [Bp,V] (Bp > B: all-gathered
  * positives for cross-GPU in-batch negatives, own rows start at label_off), n [B*k,V]; bf16_mm=1

@@ -327,3 +327,26 @@ def decoder_splade_fwd(hd: torch.Tensor, w_bf16: torch.Tensor, bias: torch.Tenso
     check(fn("snx_decoder_splade_fwd")(_p(hd), _p(w_bf16), _p(bias), _p(cu), _p(mask), _p(sparse), _p(keys), _p(tw),
                                        _p(scratch), T, nseq, max_seqlen, V, K, _stream()), "snx_decoder_splade_fwd")
     return sparse, keys, tw
+
+
+# ----------------------------------------------------------------------------- inference post-processing
+def sparse_topk(rep: torch.Tensor, allowed: torch.Tensor, k: Optional[int] = None):
+    """Per row of rep [B,V] fp32: survivors (rep > 0 and allowed[v]); more than k of them -> the k largest, weight
+    descending, ties lowest id first; else all survivors in id order (ref:benchmark/encoders.py:320-343).
+    -> (values [B,cap] fp32, ids [B,cap] int32, counts [B] int32, sorted_flags [B] int32), cap = min(k,V) or V."""
+    _chk(rep, torch.float32, "rep")
+    if rep.dim() != 2:
+        raise ValueError("sparse_topk: rep must be [B, V]")
+    B, V = rep.shape
+    _chk(allowed, torch.uint8, "allowed", (V,))
+    kk = 0 if k is None else int(k)
+    if k is not None and (kk < 1 or kk > 16384):
+        raise ValueError("sparse_topk: k must be in [1, 16384] (or None)")
+    cap = min(kk, V) if kk else V
+    vals = torch.empty((B, cap), dtype=torch.float32, device=rep.device)
+    ids = torch.empty((B, cap), dtype=torch.int32, device=rep.device)
+    cnt = torch.empty((B,), dtype=torch.int32, device=rep.device)
+    srt = torch.empty((B,), dtype=torch.int32, device=rep.device)
+    check(fn("snx_sparse_topk")(_p(rep), _p(allowed), _p(vals), _p(ids), _p(cnt), _p(srt), B, V, min(kk, V), cap,
+                                _stream()), "snx_sparse_topk")
+    return vals, ids, cnt, srt

@@ -20,6 +20,13 @@ class HashTokenizer:
     def __init__(self, vocab_size: int = 50000):
         self.vocab_size = vocab_size
         self.pad_token_id = vocab_size - 1
+        self.bos_token_id, self.eos_token_id = 0, 1
+        self.cls_token_id = self.sep_token_id = self.unk_token_id = None
+
+    def convert_ids_to_tokens(self, ids):
+        """Synthetic token texts (hashed words have none): specials as "<...>", the rest "w<id>"."""
+        names = {0: "<s>", 1: "</s>", self.pad_token_id: "<pad>"}
+        return [names.get(i, f"<unused{i}>" if i < 6 else f"w{i}") for i in ids]
 
     def __call__(self, texts, padding=True, truncation=True, max_length=64, return_tensors="pt"):
         rows = []

@@ -488,3 +488,34 @@ def synth_batch(B: int, Sq: int, Sd: int, cfg: EncoderConfig, gen: torch.Generat
         tn = 0.6 * torch.rand(B, k, generator=gen)
         out["teacher_neg_scores"] = tn if k > 1 else tn[:, 0]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Inference post-processing (ref:benchmark/encoders.py:309-345, NeuralSparseEncoderV33._encode_batch)
+# ---------------------------------------------------------------------------------------------------
+def encode_postprocess(rep_row, tokens, special_ids, top_k=None):
+    """One row of sparse_repr -> ordered list of (token, weight), restating ref:encoders.py:320-343:
+    non-zero (> 0) entries in vocab-id order (:322-323), special ids skipped (:327-328), tokens that are empty
+    or start with "[" / "<" skipped (:331), dict semantics for duplicate token strings (:332), and when more
+    than top_k entries remain the top_k by weight with Python's stable sort (:334-340) -- i.e. ties keep
+    vocab-id order."""
+    special = set(int(s) for s in special_ids)
+    d = {}
+    for idx, w in enumerate(rep_row):
+        w = float(w)
+        if not w > 0:
+            continue
+        if idx in special:
+            continue
+        tok = tokens[idx]
+        if tok and not tok.startswith(("[", "<")):
+            d[tok] = w
+    if top_k is not None and len(d) > top_k:
+        d = dict(sorted(d.items(), key=lambda kv: kv[1], reverse=True)[:top_k])
+    return list(d.items())
+
+
+def allowed_vocab_mask(tokens, special_ids):
+    """uint8 [V]: the per-id part of the filter above (what the device kernel takes)."""
+    special = set(int(s) for s in special_ids)
+    return [int(i not in special and bool(t) and not t.startswith(("[", "<"))) for i, t in enumerate(tokens)]

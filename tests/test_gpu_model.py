@@ -475,3 +475,42 @@ def test_train_epoch_vs_oracle_loop(dev, native):
     cos = num / ((den1 * den2) ** 0.5)
     _report(f"train_epoch_native{int(native)}", {"losses": got, "ref": ref_losses, "update_cos": cos})
     assert cos > 0.9, cos
+
+
+def test_inference_encoder_matches_reference_postprocessing(dev):
+    """`benchmark.encoders.NeuralSparseEncoderV33` (ref:benchmark/encoders.py:249-402): same methods / return types;
+    its device-side top-k equals the oracle's restatement of `_encode_batch` applied to the model's own
+    sparse_repr (ids, weights and order), for top_k None / small / large, via encode / encode_single /
+    encode_for_query."""
+    from benchmark.encoders import NeuralSparseEncoderV33
+    from oracle import splade_oracle as O
+    from src.model.splade_modern import SPLADEModernBERT
+    from src.train.data.collator import create_tokenizer
+    tok = create_tokenizer("hash:50000")
+    model = SPLADEModernBERT()
+    enc = NeuralSparseEncoderV33(checkpoint_path=None, device=dev, model=model, tokenizer=tok)
+    texts = ["mi355x sparse retrieval with neural encoders", "one", "a b c d e f g h i j k l m n o p q r s t u v w x y z " * 20]
+    tokens = tok.convert_ids_to_tokens(list(range(tok.vocab_size)))
+    inputs = tok(texts, max_length=enc.doc_max_length)
+    with torch.no_grad():
+        rep, _ = enc.model(input_ids=inputs["input_ids"].to(dev), attention_mask=inputs["attention_mask"].to(dev))
+    rep = rep.float().cpu()
+    for top_k in (None, 5, 100, 3000):
+        got = enc.encode(texts, batch_size=2, top_k=top_k)
+        assert isinstance(got, list) and len(got) == 3 and all(isinstance(d, dict) for d in got)
+        for j, d in enumerate(got):
+            # batches of 2 pad differently from the batch of 3 above: compare on a per-text forward when they differ
+            want = O.encode_postprocess(rep[j].tolist(), tokens, enc.special_token_ids, top_k)
+            if j < 2:
+                one = tok(texts[:2], max_length=enc.doc_max_length)
+            else:
+                one = tok(texts[2:], max_length=enc.doc_max_length)
+            with torch.no_grad():
+                r2, _ = enc.model(input_ids=one["input_ids"].to(dev), attention_mask=one["attention_mask"].to(dev))
+            want = O.encode_postprocess(r2[j % 2].float().cpu().tolist(), tokens, enc.special_token_ids, top_k)
+            assert list(d.items()) == want, (top_k, j)
+    single = enc.encode_single(texts[1], top_k=7)
+    assert isinstance(single, dict) and len(single) <= 7
+    q = enc.encode_for_query(texts[0])
+    assert isinstance(q, dict) and 0 < len(q) <= 100 and all(isinstance(v, float) for v in q.values())
+    assert list(q.values()) == sorted(q.values(), reverse=True) or len(q) < 100

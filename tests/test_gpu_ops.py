@@ -1,6 +1,7 @@
 """Op-level parity of the HIP kernels (through the C ABI) against plain PyTorch / oracle math with
 the same bf16 cast points.  Needs a real MI355X:  pytest -m gpu."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -522,3 +523,69 @@ def test_gelu_exhaustive_over_bf16_inputs(dev):
     exact = (got == grad64.float().to(BF16).double()).double().mean()
     assert exact > 0.995, exact
     assert torch.equal(du[:, 128:], y)                # dg = dy * bf16(gelu(a))
+
+
+def _topk_rows(ops, rep, allowed, k):
+    vals, ids, cnt, srt = ops.sparse_topk(rep, allowed, k)
+    out = []
+    for j in range(rep.shape[0]):
+        n = int(cnt[j])
+        out.append((ids[j, :n].tolist(), vals[j, :n].tolist(), int(srt[j])))
+    return out
+
+
+def test_sparse_topk_matches_reference_encode_batch_golden(dev):
+    """Device filter + top-k vs the reference's own `_encode_batch` outputs (g6, ref:benchmark/encoders.py:309-345)
+    and vs the oracle restatement: bit-exact ids, weights and ORDER for every row and every top_k."""
+    import json
+    GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
+    from oracle import splade_oracle as O
+    ops = _ops()
+    fx = json.load(open(os.path.join(GOLDEN_DIR, "g6_encode_topk.json")))
+    tokens, special = fx["tokens"], fx["special"]
+    rep = torch.tensor(fx["rep"], dtype=torch.float32)
+    allowed = torch.tensor(O.allowed_vocab_mask(tokens, special), dtype=torch.uint8)
+    for k, rows in fx["cases"].items():
+        top_k = None if k == "None" else min(int(k), rep.shape[1])
+        got = _topk_rows(ops, rep.to(dev), allowed.to(dev), top_k)
+        for j, want in enumerate(rows):
+            ids, ws, _ = got[j]
+            assert [tokens[i] for i in ids] == [t for t, _ in want], (k, j)
+            assert ws == [float(np.float32(w)) for _, w in want], (k, j)
+
+
+@pytest.mark.parametrize("V,k", [(50000, 100), (50000, None), (50000, 16384), (1000, 1), (4097, 4096), (50000, 3)])
+def test_sparse_topk_vs_oracle_random(dev, V, k):
+    from oracle import splade_oracle as O
+    ops = _ops()
+    g = torch.Generator().manual_seed(V + (k or 0))
+    B = 5
+    rep = torch.relu(torch.randn(B, V, generator=g) + 0.3)
+    rep[1] = (rep[1] * 4).round() / 4                      # heavy ties
+    rep[2] = torch.relu(torch.randn(V, generator=g) - 3.5)  # a handful active
+    rep[3] = 0
+    rep[4] = rep[4].to(BF16).float()                       # what the encoder emits after log1p of bf16 logits: ties
+    tokens = [("" if i % 97 == 3 else f"[x{i}]" if i % 89 == 5 else f"<y{i}>" if i % 83 == 7 else f"t{i}") for i in range(V)]
+    special = [0, 1, 2, V - 1]
+    allowed = torch.tensor(O.allowed_vocab_mask(tokens, special), dtype=torch.uint8)
+    got = _topk_rows(ops, rep.to(dev), allowed.to(dev), k)
+    for j in range(B):
+        want = O.encode_postprocess(rep[j].tolist(), tokens, special, k)
+        ids, ws, srt = got[j]
+        assert [tokens[i] for i in ids] == [t for t, _ in want]
+        assert ws == [w for _, w in want]
+        assert srt == int(k is not None and len(want) == k and sum(1 for i in range(V) if rep[j, i] > 0 and allowed[i]) > k)
+
+
+def test_sparse_topk_rejects_bad_arguments(dev):
+    ops = _ops()
+    rep = torch.zeros(2, 100, device=dev)
+    ok = torch.ones(100, dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError):
+        ops.sparse_topk(rep, ok, 0)
+    with pytest.raises(ValueError):
+        ops.sparse_topk(rep, ok, 20000)
+    with pytest.raises(ValueError):
+        ops.sparse_topk(rep, ok[:50], 5)
+    with pytest.raises(ValueError):
+        ops.sparse_topk(rep.to(BF16), ok, 5)

@@ -227,3 +227,16 @@ def test_g3_full_size_matches_reference(full_params):
         assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-12), k
     e = leaves["model.model.embeddings.tok_embeddings.weight"].grad
     np.testing.assert_allclose(e.double().norm(dim=1).float().numpy(), z["gprobe::emb_rownorm"], rtol=5e-3, atol=1e-7)
+
+
+def test_g6_encode_postprocess_matches_reference_encode_batch():
+    """oracle.encode_postprocess vs the reference's own `_encode_batch` (ref:benchmark/encoders.py:309-345) run on
+    the g6 rows: empty / dense / tied / fewer-than-k rows, special ids and "[", "<", "" tokens, k None..5000."""
+    import json
+    fx = json.load(open(os.path.join(G, "g6_encode_topk.json")))
+    for k, rows in fx["cases"].items():
+        top_k = None if k == "None" else int(k)
+        for rep_row, want in zip(fx["rep"], rows):
+            got = O.encode_postprocess(rep_row, fx["tokens"], fx["special"], top_k)
+            assert [t for t, _ in got] == [t for t, _ in want], (k,)
+            assert [w for _, w in got] == [w for _, w in want]

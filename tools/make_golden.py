@@ -426,9 +426,50 @@ def g5():
     print("g5 ok")
 
 
+def g6():
+    """Inference post-processing (ref:benchmark/encoders.py:309-345 `_encode_batch`): non-zero entries ->
+    special-token / "[..." / "<..." / empty-token filter -> optional top-k by weight.  The reference method
+    is run unmodified on an instance assembled without its constructor (which needs the hub): `model` is
+    a stand-in returning the given sparse_repr, the token table and special ids are the fixture's."""
+    _import_ref_trainer()                      # puts REF on sys.path + the sentence_transformers stub
+    import importlib
+    # `benchmark/__init__.py` pulls in boto3 / opensearch-py (absent here): register the package by path
+    # only, so that benchmark.config / benchmark.dataset / benchmark.encoders load from their own files
+    pkg = types.ModuleType("benchmark")
+    pkg.__path__ = [os.path.join(REF, "benchmark")]
+    sys.modules["benchmark"] = pkg
+    enc_mod = importlib.import_module("benchmark.encoders")
+    g = torch.Generator().manual_seed(606)
+    V, B = 700, 7
+    tokens = []
+    for i in range(V):
+        r = i % 23
+        tokens.append("" if r == 5 else f"[unused{i}]" if r == 7 else f"<tok{i}>" if r == 11 else f"w{i}")
+    special = [0, 1, 2, 3, 4, 699]
+    rep = torch.relu(torch.randn(B, V, generator=g) - 0.8)          # ~20 % active
+    rep[1] = torch.relu(torch.randn(V, generator=g) + 1.0)           # dense row
+    rep[2] = 0.0                                                     # empty row
+    rep[3] = (torch.randint(0, 4, (V,), generator=g).float() * 0.5)  # many exact ties
+    rep[4, :] = 0.0
+    rep[4, [10, 20, 30]] = torch.tensor([0.25, 0.25, 0.75])          # fewer than k
+    rep[5] = rep[5].to(torch.bfloat16).float()
+    rep[6, special] = 9.0                                            # large weights on filtered ids
+    enc = object.__new__(enc_mod.NeuralSparseEncoderV33)
+    enc.special_token_ids = set(special)
+    enc._token_lookup = tokens
+    enc.model = lambda input_ids=None, attention_mask=None: (rep, None)
+    cases = {}
+    for k in (None, 1, 3, 5, 50, 128, 699, 5000):
+        out = enc._encode_batch({"input_ids": None, "attention_mask": None}, k)
+        cases[str(k)] = [[[t, w] for t, w in d.items()] for d in out]
+    json.dump({"V": V, "tokens": tokens, "special": special, "rep": rep.tolist(), "cases": cases},
+              open(os.path.join(OUT, "g6_encode_topk.json"), "w"))
+    print("g6 ok", {k: [len(d) for d in v] for k, v in cases.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g4", "g5", "g2", "g3"]
+    which = sys.argv[1:] or ["g1", "g4", "g5", "g6", "g2", "g3"]
     for w in which:
         globals()[w]()
