@@ -14,16 +14,8 @@
 // row-major V tile with ds_read_b64_tr_b16 (hardware transpose).  The contraction index of the
 // second product is a permutation of the key index (lane group g, element j <-> key
 // 16*(2c + j/4) + 4g + j%4); both operands use the same permutation.
-#include "common.h"
+#include "attention_common.h"
 #include "snx.h"
-
-#define NEG_BIG (-1.0e30f)
-#define LOG2E 1.4426950408889634f
-#define LN2 0.6931471805599453f
-
-// 2^x on the transcendental unit (v_exp_f32); softmax runs in the log2 domain so that each
-// probability costs one FMA + one v_exp.
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // Block schedule (speed only).  Blocks b and b+8 share an XCD and its L2.  The unit of placement is
 // one (sequence, head) pair: all its 64-row tiles go to ONE XCD (K/V, or Q/dO in the dK/dV pass, are
@@ -87,12 +79,6 @@ static int attn_sched_build(AttnSched& sc, long& grid, const int32_t* groups, in
   return SNX_OK;
 }
 
-// true when every (query, key) pair of a 16-query x 64-key (or 64-query x 16-key) block lies inside
-// the band |q - k| <= window, so the per-element band test can be skipped (wave-uniform).
-__device__ __forceinline__ bool band_clean(int window, int a_lo, int a_hi, int b_lo, int b_hi) {
-  return window < 0 || (a_hi - b_lo <= window && b_hi - a_lo <= window);
-}
-
 // Register-staged tile (async-STAGE split): the global loads of tile t+1 are issued right after
 // tile t has been written to LDS and stay in flight while tile t is multiplied; they are written
 // to LDS after the next barrier.  Each thread carries 2 x 16 B of the 64x64 bf16 tile.
@@ -108,9 +94,6 @@ __device__ __forceinline__ void tile_load(TileRegs& t, const bf16_t* __restrict_
     t.v[i] = *(const bf16x8*)(base + (long)gr * row_stride + c * 8);
   }
 }
-__device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-__device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
-
 // write to a row image (k_off swizzle, ds_read_b128 rows) and/or a transposed-read image (v_off)
 __device__ __forceinline__ void tile_store(const TileRegs& t, char* lds_row, char* lds_tr) {
 #pragma unroll
@@ -120,10 +103,6 @@ __device__ __forceinline__ void tile_store(const TileRegs& t, char* lds_row, cha
     if (lds_row) *(bf16x8*)(lds_row + k_off(r, c)) = t.v[i];
     if (lds_tr) *(bf16x8*)(lds_tr + v_off(r, c)) = t.v[i];
   }
-}
-
-__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
 }
 
 // Stage one 64-row x 64-dim bf16 tile (rows key0.. of the K or V third) into LDS, swizzled.
@@ -294,19 +273,67 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   }
 }
 
+// sequence-resident fast path (attention_unit.hip): groups whose sequences fit 256 tokens
+int attn_unit_fwd(const bf16_t* qkv, const int32_t* cu_seqlens, const int64_t* mask, bf16_t* out, float* lse, int T,
+                  int heads, int window, int seq0, int nseq, int nt, hipStream_t st);
+int attn_unit_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta,
+                  const int32_t* cu_seqlens, const int64_t* mask, bf16_t* dqkv, const f32x2* rope_tab,
+                  const int32_t* pos, int T, int heads, int window, int seq0, int nseq, int nt, hipStream_t st);
+
+static bool attn_streaming_only() {
+  static const bool v = getenv("SNX_ATTN_STREAMING") != nullptr;   // A/B switch: force the tiled kernels
+  return v;
+}
+
+// validates the group table and calls f(seq_begin, nseq, max_len) per group
+template <typename F>
+static int for_each_group(const int32_t* groups, int nseq, int max_seqlen, F f) {
+  const int32_t one[4] = {1, 0, nseq, max_seqlen};
+  const int32_t* g = groups ? groups : one;
+  if (g[0] < 1 || g[0] > SNX_ATTN_MAX_GROUPS) return SNX_E_ARG;
+  int covered = 0;
+  for (int i = 0; i < g[0]; ++i) {
+    if (g[1 + 3 * i] != covered || g[2 + 3 * i] <= 0 || g[3 + 3 * i] <= 0 || g[3 + 3 * i] > max_seqlen) return SNX_E_ARG;
+    covered += g[2 + 3 * i];
+  }
+  if (covered != nseq) return SNX_E_ARG;
+  // neighbouring groups that need the same number of 64-row tiles run as one launch (the positive and the
+  // negative documents of a fused pass: 2 x 768 workgroups would each fill 1.5 rounds of the chip)
+  for (int i = 0; i < g[0];) {
+    const int seq0 = g[1 + 3 * i], nt = cdiv(g[3 + 3 * i], 64);
+    int ns = g[2 + 3 * i], ml = g[3 + 3 * i], j = i + 1;
+    while (j < g[0] && cdiv(g[3 + 3 * j], 64) == nt) {
+      ns += g[2 + 3 * j];
+      ml = ml > g[3 + 3 * j] ? ml : g[3 + 3 * j];
+      ++j;
+    }
+    const int rc = f(seq0, ns, ml);
+    if (rc != SNX_OK) return rc;
+    i = j;
+  }
+  return SNX_OK;
+}
+
 extern "C" int snx_attn_fwd_ex(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse,
                                const int32_t* groups, int32_t T, int32_t nseq, int32_t max_seqlen, int32_t heads,
                                int32_t head_dim, int32_t window, hipStream_t st) {
   if (!qkv || !cu_seqlens || !mask || !out || !lse || T <= 0 || nseq <= 0 || max_seqlen <= 0) return SNX_E_ARG;
   if (head_dim != 64 || heads <= 0) return SNX_E_SHAPE;
-  AttnSched sc;
-  long grid;
-  const int rc = attn_sched_build(sc, grid, groups, nseq, max_seqlen, heads);
-  if (rc != SNX_OK) return rc;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)qkv, cu_seqlens, mask,
-                     (bf16_t*)out, lse, T, heads, window, 0.125f, sc);
-  SNX_CHECK_LAUNCH();
-  return SNX_OK;
+  return for_each_group(groups, nseq, max_seqlen, [&](int seq0, int ns, int max_len) -> int {
+    const int nt = cdiv(max_len, 64);
+    if (nt <= 4 && !attn_streaming_only())
+      return attn_unit_fwd((const bf16_t*)qkv, cu_seqlens, mask, (bf16_t*)out, lse, T, heads, window, seq0, ns, nt, st);
+    const int32_t one[4] = {1, 0, ns, max_len};
+    AttnSched sc;
+    long grid;
+    const int rc = attn_sched_build(sc, grid, one, ns, max_len, heads);
+    if (rc != SNX_OK) return rc;
+    sc.seq0[0] = seq0;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)qkv, cu_seqlens, mask,
+                       (bf16_t*)out, lse, T, heads, window, 0.125f, sc);
+    SNX_CHECK_LAUNCH();
+    return SNX_OK;
+  });
 }
 
 extern "C" int snx_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse,
@@ -337,45 +364,6 @@ __device__ __forceinline__ void stage_dual(const bf16_t* __restrict__ base, long
     const bf16x8 v = *(const bf16x8*)(base + (long)gr * row_stride + c * 8);
     if (lds_row) *(bf16x8*)(lds_row + k_off(r, c)) = v;
     if (lds_tr) *(bf16x8*)(lds_tr + v_off(r, c)) = v;
-  }
-}
-
-// A-operand fragment of the TRANSPOSE of a [64 rows][64 d] tile (v_off image): MFMA row index =
-// d (16*dt + lane&15), contraction elements = tile rows 16*(2c + j/4) + 4g + j%4.
-__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int dt, int c, int lane) {
-  const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int r0 = 16 * (2 * c) + 4 * g + tq, r1 = r0 + 16;
-  const int chunk = 2 * dt + (tp >> 1);
-  const bf16x4 a0 = lds_tr16(tile + v_off(r0, chunk) + (tp & 1) * 8);
-  const bf16x4 a1 = lds_tr16(tile + v_off(r1, chunk) + (tp & 1) * 8);
-  return (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-}
-
-// Epilogue of dQ / dK / dV: this lane holds grad[d = 16*dt + 4g + r] of one token row.  With a
-// RoPE table the transposed rotation (backward of hf:196-219) is applied to the bf16-rounded
-// gradient before the store: the pair (d, d+32) lives in accumulators dt and dt+2 of the same lane.
-__device__ __forceinline__ void store_grad_rows(bf16_t* orow, const f32x4 (&acc)[4], float scale,
-                                                const f32x2* __restrict__ rope_tab, int p, int g) {
-  if (rope_tab) {
-    const f32x2* cs = rope_tab + (long)p * 32 + g * 4;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      bf16x4 lo, hi;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x2 t = cs[dt * 16 + r];
-        const float y1 = rbf(acc[dt][r] * scale), y2 = rbf(acc[dt + 2][r] * scale);
-        lo[r] = f2bf(y1 * t[0] + y2 * t[1]);
-        hi[r] = f2bf(y2 * t[0] - y1 * t[1]);
-      }
-      *(bf16x4*)(orow + dt * 16) = lo;
-      *(bf16x4*)(orow + (dt + 2) * 16) = hi;
-    }
-  } else {
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      *(bf16x4*)(orow + dt * 16) = (bf16x4){f2bf(acc[dt][0] * scale), f2bf(acc[dt][1] * scale),
-                                            f2bf(acc[dt][2] * scale), f2bf(acc[dt][3] * scale)};
   }
 }
 
@@ -632,20 +620,28 @@ extern "C" int snx_attn_bwd_ex(const void* qkv, const void* out, const void* dou
   if ((rope_tab == nullptr) != (pos == nullptr)) return SNX_E_ARG;
   if (!qkv || !out || !dout || !lse || !cu_seqlens || !mask || !delta_scratch || !dqkv) return SNX_E_ARG;
   if (T <= 0 || nseq <= 0 || max_seqlen <= 0 || heads <= 0 || head_dim != 64) return SNX_E_SHAPE;
-  AttnSched sc;
-  long grid_l;
-  const int rc = attn_sched_build(sc, grid_l, groups, nseq, max_seqlen, heads);
-  if (rc != SNX_OK) return rc;
-  const dim3 grid((unsigned)grid_l);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
-                     (const bf16_t*)dout, lse, delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv,
-                     (const f32x2*)rope_tab, pos, T, heads, window, 0.125f, sc);
-  SNX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
-                     delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, (const f32x2*)rope_tab, pos, T, heads, window,
-                     0.125f, sc);
-  SNX_CHECK_LAUNCH();
-  return SNX_OK;
+  return for_each_group(groups, nseq, max_seqlen, [&](int seq0, int ns, int max_len) -> int {
+    const int nt = cdiv(max_len, 64);
+    if (nt <= 4 && !attn_streaming_only())
+      return attn_unit_bwd((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta_scratch, cu_seqlens,
+                           mask, (bf16_t*)dqkv, (const f32x2*)rope_tab, pos, T, heads, window, seq0, ns, nt, st);
+    const int32_t one[4] = {1, 0, ns, max_len};
+    AttnSched sc;
+    long grid_l;
+    const int rc = attn_sched_build(sc, grid_l, one, ns, max_len, heads);
+    if (rc != SNX_OK) return rc;
+    sc.seq0[0] = seq0;
+    const dim3 grid((unsigned)grid_l);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv,
+                       (const f32x2*)rope_tab, pos, T, heads, window, 0.125f, sc);
+    SNX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                       delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, (const f32x2*)rope_tab, pos, T, heads, window,
+                       0.125f, sc);
+    SNX_CHECK_LAUNCH();
+    return SNX_OK;
+  });
 }
 
 extern "C" int snx_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
