@@ -273,21 +273,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   }
 }
 
-// sequence-resident fast path (attention_unit.hip): groups whose sequences fit 256 tokens
+// sequence-resident fast path (attention_unit.hip): one launch for all groups whose sequences fit 256 tokens
 int attn_unit_fwd(const bf16_t* qkv, const int32_t* cu_seqlens, const int64_t* mask, bf16_t* out, float* lse, int T,
-                  int heads, int window, int seq0, int nseq, int nt, hipStream_t st);
+                  int heads, int window, const int32_t* groups, hipStream_t st);
 int attn_unit_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta,
                   const int32_t* cu_seqlens, const int64_t* mask, bf16_t* dqkv, const f32x2* rope_tab,
-                  const int32_t* pos, int T, int heads, int window, int seq0, int nseq, int nt, hipStream_t st);
+                  const int32_t* pos, int T, int heads, int window, const int32_t* groups, hipStream_t st);
 
 static bool attn_streaming_only() {
   static const bool v = getenv("SNX_ATTN_STREAMING") != nullptr;   // A/B switch: force the tiled kernels
   return v;
 }
 
-// validates the group table and calls f(seq_begin, nseq, max_len) per group
-template <typename F>
-static int for_each_group(const int32_t* groups, int nseq, int max_seqlen, F f) {
+// Validates the group table, then calls resident(sub-table of the groups of <= 256 tokens) once and
+// streaming(seq_begin, nseq, max_len) for every longer group.
+template <typename FR, typename FS>
+static int route_groups(const int32_t* groups, int nseq, int max_seqlen, FR resident, FS streaming) {
   const int32_t one[4] = {1, 0, nseq, max_seqlen};
   const int32_t* g = groups ? groups : one;
   if (g[0] < 1 || g[0] > SNX_ATTN_MAX_GROUPS) return SNX_E_ARG;
@@ -297,21 +298,19 @@ static int for_each_group(const int32_t* groups, int nseq, int max_seqlen, F f) 
     covered += g[2 + 3 * i];
   }
   if (covered != nseq) return SNX_E_ARG;
-  // neighbouring groups that need the same number of 64-row tiles run as one launch (the positive and the
-  // negative documents of a fused pass: 2 x 768 workgroups would each fill 1.5 rounds of the chip)
-  for (int i = 0; i < g[0];) {
-    const int seq0 = g[1 + 3 * i], nt = cdiv(g[3 + 3 * i], 64);
-    int ns = g[2 + 3 * i], ml = g[3 + 3 * i], j = i + 1;
-    while (j < g[0] && cdiv(g[3 + 3 * j], 64) == nt) {
-      ns += g[2 + 3 * j];
-      ml = ml > g[3 + 3 * j] ? ml : g[3 + 3 * j];
-      ++j;
+  int32_t sub[1 + 3 * SNX_ATTN_MAX_GROUPS];
+  sub[0] = 0;
+  for (int i = 0; i < g[0]; ++i) {
+    const int32_t* e = g + 1 + 3 * i;
+    if (e[2] <= 256 && !attn_streaming_only()) {
+      int32_t* d = sub + 1 + 3 * sub[0]++;
+      d[0] = e[0]; d[1] = e[1]; d[2] = e[2];
+    } else {
+      const int rc = streaming(e[0], e[1], e[2]);
+      if (rc != SNX_OK) return rc;
     }
-    const int rc = f(seq0, ns, ml);
-    if (rc != SNX_OK) return rc;
-    i = j;
   }
-  return SNX_OK;
+  return sub[0] ? resident(sub) : SNX_OK;
 }
 
 extern "C" int snx_attn_fwd_ex(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse,
@@ -319,21 +318,23 @@ extern "C" int snx_attn_fwd_ex(const void* qkv, const int32_t* cu_seqlens, const
                                int32_t head_dim, int32_t window, hipStream_t st) {
   if (!qkv || !cu_seqlens || !mask || !out || !lse || T <= 0 || nseq <= 0 || max_seqlen <= 0) return SNX_E_ARG;
   if (head_dim != 64 || heads <= 0) return SNX_E_SHAPE;
-  return for_each_group(groups, nseq, max_seqlen, [&](int seq0, int ns, int max_len) -> int {
-    const int nt = cdiv(max_len, 64);
-    if (nt <= 4 && !attn_streaming_only())
-      return attn_unit_fwd((const bf16_t*)qkv, cu_seqlens, mask, (bf16_t*)out, lse, T, heads, window, seq0, ns, nt, st);
-    const int32_t one[4] = {1, 0, ns, max_len};
-    AttnSched sc;
-    long grid;
-    const int rc = attn_sched_build(sc, grid, one, ns, max_len, heads);
-    if (rc != SNX_OK) return rc;
-    sc.seq0[0] = seq0;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)qkv, cu_seqlens, mask,
-                       (bf16_t*)out, lse, T, heads, window, 0.125f, sc);
-    SNX_CHECK_LAUNCH();
-    return SNX_OK;
-  });
+  return route_groups(
+      groups, nseq, max_seqlen,
+      [&](const int32_t* sub) -> int {
+        return attn_unit_fwd((const bf16_t*)qkv, cu_seqlens, mask, (bf16_t*)out, lse, T, heads, window, sub, st);
+      },
+      [&](int seq0, int ns, int max_len) -> int {
+        const int32_t one[4] = {1, 0, ns, max_len};
+        AttnSched sc;
+        long grid;
+        const int rc = attn_sched_build(sc, grid, one, ns, max_len, heads);
+        if (rc != SNX_OK) return rc;
+        sc.seq0[0] = seq0;
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)qkv, cu_seqlens,
+                           mask, (bf16_t*)out, lse, T, heads, window, 0.125f, sc);
+        SNX_CHECK_LAUNCH();
+        return SNX_OK;
+      });
 }
 
 extern "C" int snx_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse,
@@ -620,28 +621,30 @@ extern "C" int snx_attn_bwd_ex(const void* qkv, const void* out, const void* dou
   if ((rope_tab == nullptr) != (pos == nullptr)) return SNX_E_ARG;
   if (!qkv || !out || !dout || !lse || !cu_seqlens || !mask || !delta_scratch || !dqkv) return SNX_E_ARG;
   if (T <= 0 || nseq <= 0 || max_seqlen <= 0 || heads <= 0 || head_dim != 64) return SNX_E_SHAPE;
-  return for_each_group(groups, nseq, max_seqlen, [&](int seq0, int ns, int max_len) -> int {
-    const int nt = cdiv(max_len, 64);
-    if (nt <= 4 && !attn_streaming_only())
-      return attn_unit_bwd((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta_scratch, cu_seqlens,
-                           mask, (bf16_t*)dqkv, (const f32x2*)rope_tab, pos, T, heads, window, seq0, ns, nt, st);
-    const int32_t one[4] = {1, 0, ns, max_len};
-    AttnSched sc;
-    long grid_l;
-    const int rc = attn_sched_build(sc, grid_l, one, ns, max_len, heads);
-    if (rc != SNX_OK) return rc;
-    sc.seq0[0] = seq0;
-    const dim3 grid((unsigned)grid_l);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
-                       (const bf16_t*)dout, lse, delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv,
-                       (const f32x2*)rope_tab, pos, T, heads, window, 0.125f, sc);
-    SNX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
-                       delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, (const f32x2*)rope_tab, pos, T, heads, window,
-                       0.125f, sc);
-    SNX_CHECK_LAUNCH();
-    return SNX_OK;
-  });
+  return route_groups(
+      groups, nseq, max_seqlen,
+      [&](const int32_t* sub) -> int {
+        return attn_unit_bwd((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta_scratch,
+                             cu_seqlens, mask, (bf16_t*)dqkv, (const f32x2*)rope_tab, pos, T, heads, window, sub, st);
+      },
+      [&](int seq0, int ns, int max_len) -> int {
+        const int32_t one[4] = {1, 0, ns, max_len};
+        AttnSched sc;
+        long grid_l;
+        const int rc = attn_sched_build(sc, grid_l, one, ns, max_len, heads);
+        if (rc != SNX_OK) return rc;
+        sc.seq0[0] = seq0;
+        const dim3 grid((unsigned)grid_l);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                           (const bf16_t*)dout, lse, delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv,
+                           (const f32x2*)rope_tab, pos, T, heads, window, 0.125f, sc);
+        SNX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                           delta_scratch, cu_seqlens, mask, (bf16_t*)dqkv, (const f32x2*)rope_tab, pos, T, heads,
+                           window, 0.125f, sc);
+        SNX_CHECK_LAUNCH();
+        return SNX_OK;
+      });
 }
 
 extern "C" int snx_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,

@@ -5,8 +5,8 @@
 //   streaming : one workgroup per 64-row tile; K/V (or Q/dO) re-staged tile by tile through LDS by
 //               every workgroup of the sequence, two __syncthreads per tile.  PMC: waves parked in
 //               s_waitcnt / s_barrier 54 % of their cycles, VALU 43 % and MFMA 15 % busy.
-//   resident  : one workgroup per (sequence, head) with NT x 2 waves; the sequence's whole K and V
-//               (or Q and dO) -- NT x 8 KiB each -- are loaded ONCE, one barrier, then every wave
+//   resident  : a (sequence, head) unit gets ntu x 2 waves (ntu = its number of 64-row tiles); its whole K and V
+//               (or Q and dO) -- ntu x 8 KiB each -- are loaded ONCE, one barrier, then every wave
 //               walks the key (query) tiles of its two 16-row groups straight out of LDS with no
 //               further synchronisation; the band of a sliding-window layer is resolved per 16 rows,
 //               not per 64-row tile.  Two workgroups fit a CU (2 x 64 KiB LDS, <= 128 VGPRs at 4
@@ -21,49 +21,80 @@
 namespace {
 
 constexpr int TILE_BYTES = 64 * 128;
+#define SNX_ATTN_UNIT_GROUPS 8
 
-// Load rows [0, NT*64) x 64 d of one tensor (row stride rs elements) into a v_off image; rows past the
-// sequence repeat its last row (their products are masked).
-template <int NT, int RG>
-__device__ __forceinline__ void load_image(const bf16_t* __restrict__ base, long rs, int slen, char* img) {
-  constexpr int NTHR = NT * 256 / RG;
+constexpr int NTMAX = 4;                       // tiles per workgroup: 256 rows of K and V (or Q and dO) = 64 KiB
+constexpr int IMG_BYTES = 2 * NTMAX * TILE_BYTES;
+
+// One launch serves every sequence group of <= 256 tokens: a workgroup holds NTMAX / ntu units
+// ((sequence, head) pairs of ntu 64-row tiles each), e.g. one 256-token document or four 64-token queries,
+// each unit with its own waves and its own slice of the LDS images.  Longest group first.
+struct UnitSched {
+  int n;
+  int seq0[SNX_ATTN_UNIT_GROUPS], units[SNX_ATTN_UNIT_GROUPS], ntu[SNX_ATTN_UNIT_GROUPS];
+  int bend[SNX_ATTN_UNIT_GROUPS];              // exclusive prefix end of the group's workgroups
+};
+
+struct Slot {
+  int head, s0, slen, ntu;
+  int wpu, lw, lt, slot;                       // waves per unit, wave / thread index inside the unit, unit slot
+  bool live;
+};
+// RG = 16-row groups per wave (waves per unit = ntu * 4 / RG)
+template <int RG>
+__device__ __forceinline__ Slot slot_of_block(const UnitSched& sc, const int32_t* __restrict__ cu_seqlens, int heads) {
+  int g = 0, b0 = 0;
+#pragma unroll
+  for (int i = 0; i < SNX_ATTN_UNIT_GROUPS - 1; ++i)
+    if (i + 1 < sc.n && (int)blockIdx.x >= sc.bend[i]) { g = i + 1; b0 = sc.bend[i]; }
+  Slot t;
+  t.ntu = sc.ntu[g];
+  const int upb = NTMAX / t.ntu;
+  t.wpu = t.ntu * 4 / RG;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the unit bookkeeping in SGPRs
+  t.slot = wave / t.wpu;
+  t.lw = wave - t.slot * t.wpu;
+  t.lt = (int)threadIdx.x - t.slot * t.wpu * 64;
+  const int unit = ((int)blockIdx.x - b0) * upb + t.slot;
+  t.live = t.slot < upb && unit < sc.units[g];
+  const int seq = sc.seq0[g] + (t.live ? unit / heads : 0);
+  t.head = t.live ? unit % heads : 0;
+  t.s0 = cu_seqlens[seq];
+  const int n = cu_seqlens[seq + 1] - t.s0;
+  t.slen = n < t.ntu * 64 ? n : t.ntu * 64;    // contract: the group's max_len covers its sequences
+  return t;
+}
+
+// Load rows [0, ntu*64) x 64 d of one tensor (row stride rs elements) into the unit's v_off image; rows past
+// the sequence repeat its last row (their products are masked).  2*RG 16-B pieces per thread.
+template <int RG>
+__device__ __forceinline__ void load_image(const bf16_t* __restrict__ base, long rs, const Slot& t, char* img) {
+  const int nthr = t.wpu * 64;
   bf16x8 v[2 * RG];
 #pragma unroll
   for (int i = 0; i < 2 * RG; ++i) {
-    const int id = threadIdx.x + i * NTHR;
+    const int id = t.lt + i * nthr;
     const int r = id >> 3, c = id & 7;
-    const int gr = r < slen ? r : slen - 1;
+    const int gr = r < t.slen ? r : t.slen - 1;
     v[i] = *(const bf16x8*)(base + (long)gr * rs + c * 8);
   }
 #pragma unroll
   for (int i = 0; i < 2 * RG; ++i) {
-    const int id = threadIdx.x + i * NTHR;
+    const int id = t.lt + i * nthr;
     *(bf16x8*)(img + v_off(id >> 3, id & 7)) = v[i];
   }
 }
 
-// key validity (inside the sequence and not masked) per key + "all 64 valid" per tile
-template <int NT>
-__device__ __forceinline__ void load_valid(const int64_t* __restrict__ mask, int s0, int slen, unsigned char* sValid,
+// key validity (inside the sequence and not masked) per key + "all 64 valid" per tile, for the unit
+__device__ __forceinline__ void load_valid(const int64_t* __restrict__ mask, const Slot& t, unsigned char* sValid,
                                            int* sAll) {
-  if (threadIdx.x < NT * 64) {
-    const int key = threadIdx.x;
-    const bool v = key < slen && mask[s0 + key] != 0;
+  if (t.lt < t.ntu * 64) {                     // whole waves: ntu * 64 and the unit's first thread are multiples of 64
+    const int key = t.lt;
+    const bool v = key < t.slen && mask[t.s0 + key] != 0;
     sValid[key] = v ? 1 : 0;
     const unsigned long long all = __ballot(v);
-    if ((threadIdx.x & 63) == 0) sAll[threadIdx.x >> 6] = (all == ~0ull) ? 1 : 0;
+    if ((t.lt & 63) == 0) sAll[t.lt >> 6] = (all == ~0ull) ? 1 : 0;
   }
-}
-
-struct Unit { int seq, head, s0, slen; };
-__device__ __forceinline__ Unit unit_of_block(const int32_t* __restrict__ cu_seqlens, int seq0, int heads, int max_rows) {
-  Unit u;
-  u.seq = seq0 + blockIdx.x / heads;
-  u.head = blockIdx.x % heads;
-  u.s0 = cu_seqlens[u.seq];
-  const int n = cu_seqlens[u.seq + 1] - u.s0;
-  u.slen = n < max_rows ? n : max_rows;            // contract: the group's max_len covers its sequences
-  return u;
 }
 
 // tile range [lo, hi] a 16-row wave needs (whole sequence on global layers, the band on local ones)
@@ -78,29 +109,33 @@ __device__ __forceinline__ void tile_range(int window, int row_lo, int slen, int
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int NT>
-__global__ __launch_bounds__(NT * 128, 4) void attn_fwd_unit_kernel(const bf16_t* __restrict__ qkv,
-                                                                const int32_t* __restrict__ cu_seqlens,
-                                                                const int64_t* __restrict__ mask,
-                                                                bf16_t* __restrict__ out, float* __restrict__ lse, int T,
-                                                                int heads, int window, float scale, int seq0) {
+__global__ __launch_bounds__(NTMAX * 128, 4) void attn_fwd_unit_kernel(const bf16_t* __restrict__ qkv,
+                                                                       const int32_t* __restrict__ cu_seqlens,
+                                                                       const int64_t* __restrict__ mask,
+                                                                       bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                                       int T, int heads, int window, float scale,
+                                                                       const UnitSched sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;
-  char* sV = smem + NT * TILE_BYTES;
-  unsigned char* sValid = (unsigned char*)(smem + 2 * NT * TILE_BYTES);
-  int* sAll = (int*)(sValid + NT * 64);
-  const Unit u = unit_of_block(cu_seqlens, seq0, heads, NT * 64);
-  const int s0 = u.s0, slen = u.slen, head = u.head;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const Slot t = slot_of_block<2>(sched, cu_seqlens, heads);
+  const int ntu = t.ntu;
+  char* sK = smem + t.slot * 2 * ntu * TILE_BYTES;
+  char* sV = sK + ntu * TILE_BYTES;
+  unsigned char* sValid = (unsigned char*)(smem + IMG_BYTES) + t.slot * ntu * 64;
+  int* sAll = (int*)(smem + IMG_BYTES + NTMAX * 64) + t.slot * ntu;
+  const int s0 = t.s0, slen = t.slen, head = t.head;
+  const int lane = threadIdx.x & 63;
   const int g = lane >> 4, li = lane & 15;
   const int H = heads * 64;
   const long rs = 3L * H;
   const bf16_t* qbase = qkv + (long)s0 * rs + head * 64;
-  load_image<NT, 2>(qbase + H, rs, slen, sK);
-  load_image<NT, 2>(qbase + 2 * H, rs, slen, sV);
-  load_valid<NT>(mask, s0, slen, sValid, sAll);
+  if (t.live) {
+    load_image<2>(qbase + H, rs, t, sK);
+    load_image<2>(qbase + 2 * H, rs, t, sV);
+    load_valid(mask, t, sValid, sAll);
+  }
   __syncthreads();
-  for (int rg = wave; rg < NT * 4; rg += NT * 2) {          // this wave's 16-row groups
+  if (!t.live) return;
+  for (int rg = t.lw; rg < ntu * 4; rg += t.wpu) {          // this wave's 16-row groups
   const int row_lo = rg * 16;
   if (row_lo >= slen) break;
   const int qpos = row_lo + li;
@@ -116,6 +151,8 @@ __global__ __launch_bounds__(NT * 128, 4) void attn_fwd_unit_kernel(const bf16_t
   for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_run = NEG_BIG, l_run = 0.f;
   const float c2 = scale * LOG2E;
+  const int weff = window >= 0 ? window : (1 << 20);    // global layers: a band that never cuts
+  const unsigned w2 = 2u * (unsigned)weff;
   for (int j = j_lo; j <= j_hi; ++j) {
     const int key0 = j * 64;
     const char* tK = sK + j * TILE_BYTES;
@@ -130,9 +167,11 @@ __global__ __launch_bounds__(NT * 128, 4) void attn_fwd_unit_kernel(const bf16_t
         s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[c], s[kt], 0, 0, 0);
       }
     }
-    const bool clean = sAll[j] && band_clean(window, row_lo, row_lo + 15, key0, key0 + 63);
+    const bool all_valid = sAll[j] != 0;
+    const int mode = !all_valid ? 2 : band_clean(window, row_lo, row_lo + 15, key0, key0 + 63) ? 0 : 1;
+    const int ub = qpos - key0 - g * 4 + weff;          // (unsigned)(ub - (16 kt + r)) <= 2 weff  <=>  in band
     float mx = NEG_BIG;
-    if (clean) {
+    if (mode == 0) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -140,18 +179,22 @@ __global__ __launch_bounds__(NT * 128, 4) void attn_fwd_unit_kernel(const bf16_t
           s[kt][r] *= c2;
           mx = fmaxf(mx, s[kt][r]);
         }
+    } else if (mode == 1) {                             // all keys are tokens: only the band cuts
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = (unsigned)(ub - (kt * 16 + r)) <= w2 ? s[kt][r] * c2 : NEG_BIG;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
     } else {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         const uint32_t vm = *(const uint32_t*)(sValid + key0 + kt * 16 + g * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = key0 + kt * 16 + g * 4 + r;
-          bool ok = (vm >> (8 * r)) & 1;
-          if (window >= 0) {
-            const int dlt = qpos - key;
-            ok = ok && (dlt <= window) && (dlt >= -window);
-          }
+          const bool ok = ((vm >> (8 * r)) & 1) && (unsigned)(ub - (kt * 16 + r)) <= w2;
           const float v = ok ? s[kt][r] * c2 : NEG_BIG;
           s[kt][r] = v;
           mx = fmaxf(mx, v);
@@ -196,29 +239,32 @@ __global__ __launch_bounds__(NT * 128, 4) void attn_fwd_unit_kernel(const bf16_t
 }
 
 // --------------------------------------------------------------------------------------- backward dQ
-template <int NT>
-__global__ __launch_bounds__(NT * 128, 4) void attn_bwd_dq_unit_kernel(
+__global__ __launch_bounds__(NTMAX * 128, 4) void attn_bwd_dq_unit_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ delta, const int32_t* __restrict__ cu_seqlens,
     const int64_t* __restrict__ mask, bf16_t* __restrict__ dqkv, const f32x2* __restrict__ rope_tab,
-    const int32_t* __restrict__ pos, int T, int heads, int window, float scale, int seq0) {
+    const int32_t* __restrict__ pos, int T, int heads, int window, float scale, const UnitSched sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;
-  char* sV = smem + NT * TILE_BYTES;
-  unsigned char* sValid = (unsigned char*)(smem + 2 * NT * TILE_BYTES);
-  int* sAll = (int*)(sValid + NT * 64);
-  const Unit u = unit_of_block(cu_seqlens, seq0, heads, NT * 64);
-  const int s0 = u.s0, slen = u.slen, head = u.head;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const Slot t = slot_of_block<2>(sched, cu_seqlens, heads);
+  const int ntu = t.ntu;
+  char* sK = smem + t.slot * 2 * ntu * TILE_BYTES;
+  char* sV = sK + ntu * TILE_BYTES;
+  unsigned char* sValid = (unsigned char*)(smem + IMG_BYTES) + t.slot * ntu * 64;
+  int* sAll = (int*)(smem + IMG_BYTES + NTMAX * 64) + t.slot * ntu;
+  const int s0 = t.s0, slen = t.slen, head = t.head;
+  const int lane = threadIdx.x & 63;
   const int g = lane >> 4, li = lane & 15;
   const int H = heads * 64;
   const long rs = 3L * H;
   const bf16_t* qbase = qkv + (long)s0 * rs + head * 64;
-  load_image<NT, 2>(qbase + H, rs, slen, sK);
-  load_image<NT, 2>(qbase + 2 * H, rs, slen, sV);
-  load_valid<NT>(mask, s0, slen, sValid, sAll);
+  if (t.live) {
+    load_image<2>(qbase + H, rs, t, sK);
+    load_image<2>(qbase + 2 * H, rs, t, sV);
+    load_valid(mask, t, sValid, sAll);
+  }
   __syncthreads();
-  for (int rg = wave; rg < NT * 4; rg += NT * 2) {          // this wave's 16-row groups
+  if (!t.live) return;
+  for (int rg = t.lw; rg < ntu * 4; rg += t.wpu) {          // this wave's 16-row groups
   const int row_lo = rg * 16;
   if (row_lo >= slen) break;
   const int qpos = row_lo + li;
@@ -243,6 +289,8 @@ __global__ __launch_bounds__(NT * 128, 4) void attn_bwd_dq_unit_kernel(
   int j_lo, j_hi;
   tile_range(window, row_lo, slen, j_lo, j_hi);
   const float c2 = scale * LOG2E;
+  const int weff = window >= 0 ? window : (1 << 20);    // global layers: a band that never cuts
+  const unsigned w2 = 2u * (unsigned)weff;
   f32x4 dq[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -250,10 +298,14 @@ __global__ __launch_bounds__(NT * 128, 4) void attn_bwd_dq_unit_kernel(
     const int key0 = j * 64;
     const char* tK = sK + j * TILE_BYTES;
     const char* tV = sV + j * TILE_BYTES;
-    const bool clean = sAll[j] && band_clean(window, row_lo, row_lo + 15, key0, key0 + 63);
-    // the whole tile body exists twice (CLEAN: no per-element mask) so that neither copy branches inside
-    auto tile = [&](auto clean_tag) {
-      constexpr bool CLEAN = decltype(clean_tag)::value;
+    // The tile body exists three times so that no copy branches inside: MODE 0 = every (query, key) pair counts,
+    // MODE 1 = all 64 keys are real tokens, only the band |q - k| <= window cuts (one unsigned compare per
+    // element: the edge tiles of every sliding-window layer), MODE 2 = band and key validity.
+    const bool all_valid = sAll[j] != 0;
+    const int mode = !all_valid ? 2 : band_clean(window, row_lo, row_lo + 15, key0, key0 + 63) ? 0 : 1;
+    const int ub = qpos - key0 - g * 4 + weff;          // (unsigned)(ub - (16 kt + r)) <= 2 weff  <=>  in band
+    auto tile = [&](auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
       bf16x8 dsb[2];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
@@ -266,17 +318,13 @@ __global__ __launch_bounds__(NT * 128, 4) void attn_bwd_dq_unit_kernel(
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[c], dp, 0, 0, 0);
         }
         uint32_t vm = 0x01010101u;
-        if (!CLEAN) vm = *(const uint32_t*)(sValid + key0 + kt * 16 + g * 4);
+        if (MODE == 2) vm = *(const uint32_t*)(sValid + key0 + kt * 16 + g * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float p = fast_exp2(fmaf(s[r], c2, -lse2_q));
-          if (!CLEAN) {
-            const int key = key0 + kt * 16 + g * 4 + r;
-            bool ok = (vm >> (8 * r)) & 1;
-            if (window >= 0) {
-              const int dlt = qpos - key;
-              ok = ok && (dlt <= window) && (dlt >= -window);
-            }
+          if (MODE >= 1) {
+            bool ok = (unsigned)(ub - (kt * 16 + r)) <= w2;
+            if (MODE == 2) ok = ok && ((vm >> (8 * r)) & 1);
             p = ok ? p : 0.f;
           }
           dsb[kt >> 1][(kt & 1) * 4 + r] = f2bf(p * (dp[r] - dl_q));
@@ -288,7 +336,9 @@ __global__ __launch_bounds__(NT * 128, 4) void attn_bwd_dq_unit_kernel(
         for (int c = 0; c < 2; ++c)
           dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(tK, d, c, lane), dsb[c], dq[d], 0, 0, 0);
     };
-    if (clean) tile(std::true_type{}); else tile(std::false_type{});
+    if (mode == 0) tile(std::integral_constant<int, 0>{});
+    else if (mode == 1) tile(std::integral_constant<int, 1>{});
+    else tile(std::integral_constant<int, 2>{});
   }
   if (qpos < slen) {
     bf16_t* orow = dqkv + (long)(s0 + qpos) * rs + head * 64 + g * 4;
@@ -298,33 +348,36 @@ __global__ __launch_bounds__(NT * 128, 4) void attn_bwd_dq_unit_kernel(
 }
 
 // ------------------------------------------------------------------------------------ backward dK, dV
-template <int NT>
-__global__ __launch_bounds__(NT * 256) void attn_bwd_dkv_unit_kernel(
+__global__ __launch_bounds__(NTMAX * 256) void attn_bwd_dkv_unit_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, const int32_t* __restrict__ cu_seqlens, const int64_t* __restrict__ mask,
     bf16_t* __restrict__ dqkv, const f32x2* __restrict__ rope_tab, const int32_t* __restrict__ pos, int T,
-    int heads, int window, float scale, int seq0) {
+    int heads, int window, float scale, const UnitSched sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sQ = smem;
-  char* sO = smem + NT * TILE_BYTES;
-  float* sLse = (float*)(smem + 2 * NT * TILE_BYTES);
-  float* sDel = sLse + NT * 64;
-  const Unit u = unit_of_block(cu_seqlens, seq0, heads, NT * 64);
-  const int s0 = u.s0, slen = u.slen, head = u.head;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const Slot t = slot_of_block<1>(sched, cu_seqlens, heads);
+  const int ntu = t.ntu;
+  char* sQ = smem + t.slot * 2 * ntu * TILE_BYTES;
+  char* sO = sQ + ntu * TILE_BYTES;
+  float* sLse = (float*)(smem + IMG_BYTES) + t.slot * ntu * 64;
+  float* sDel = (float*)(smem + IMG_BYTES) + NTMAX * 64 + t.slot * ntu * 64;
+  const int s0 = t.s0, slen = t.slen, head = t.head;
+  const int lane = threadIdx.x & 63;
   const int g = lane >> 4, li = lane & 15;
   const int H = heads * 64;
   const long rs = 3L * H;
   const bf16_t* qbase = qkv + (long)s0 * rs + head * 64;
-  load_image<NT, 1>(qbase, rs, slen, sQ);
-  load_image<NT, 1>(dout + (long)s0 * H + head * 64, H, slen, sO);
-  if (threadIdx.x < NT * 64) {
-    const int qc = (int)threadIdx.x < slen ? (int)threadIdx.x : slen - 1;
-    sLse[threadIdx.x] = lse[(long)head * T + s0 + qc] * LOG2E;       // log2 domain
-    sDel[threadIdx.x] = delta[(long)head * T + s0 + qc];
+  if (t.live) {
+    load_image<1>(qbase, rs, t, sQ);
+    load_image<1>(dout + (long)s0 * H + head * 64, H, t, sO);
+    if (t.lt < ntu * 64) {
+      const int qc = t.lt < slen ? t.lt : slen - 1;
+      sLse[t.lt] = lse[(long)head * T + s0 + qc] * LOG2E;       // log2 domain
+      sDel[t.lt] = delta[(long)head * T + s0 + qc];
+    }
   }
   __syncthreads();
-  for (int rg = wave; rg < NT * 4; rg += NT * 4) {          // one 16-row group per wave (register budget)
+  if (!t.live) return;
+  for (int rg = t.lw; rg < ntu * 4; rg += t.wpu) {          // one 16-row group per wave (register budget)
   const int row_lo = rg * 16;
   if (row_lo >= slen) break;
   const int kpos = row_lo + li;
@@ -342,6 +395,8 @@ __global__ __launch_bounds__(NT * 256) void attn_bwd_dkv_unit_kernel(
   int i_lo, i_hi;
   tile_range(window, row_lo, slen, i_lo, i_hi);
   const float c2 = scale * LOG2E;
+  const int weff = window >= 0 ? window : (1 << 20);    // global layers: a band that never cuts
+  const unsigned w2 = 2u * (unsigned)weff;
   f32x4 dk[4], dv[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
@@ -353,43 +408,44 @@ __global__ __launch_bounds__(NT * 256) void attn_bwd_dkv_unit_kernel(
     const char* tQ = sQ + i * TILE_BYTES;
     const char* tO = sO + i * TILE_BYTES;
     // no masking needed when all 64 queries exist, this wave's 16 keys are all valid and in band
-    const bool clean = (q0 + 63 < slen) && wave_keys_valid && band_clean(window, q0, q0 + 63, row_lo, row_lo + 15);
-    bf16x8 pb[2], dsb[2];
+    const bool simple = (q0 + 63 < slen) && wave_keys_valid;        // every (query, key) pair of the tile exists
+    const bool clean = simple && band_clean(window, q0, q0 + 63, row_lo, row_lo + 15);
+    const int ub = q0 + g * 4 - kpos + weff;                        // (unsigned)(ub + 16 qt + r) <= 2 weff  <=>  in band
+    // two halves of 32 queries: each half's P / dS (one bf16x8 per lane) feeds its 32-deep dV / dK MFMAs at once
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int hq = 0; hq < 2; ++hq) {
+      bf16x8 pb, dsb;
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const bf16x8 qfr = *(const bf16x8*)(tQ + v_off(qt * 16 + li, 4 * c + g));
-        const bf16x8 ofr = *(const bf16x8*)(tO + v_off(qt * 16 + li, 4 * c + g));
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[c], s, 0, 0, 0);     // S[q][key]
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[c], dp, 0, 0, 0);   // dP[q][key]
-      }
-      const f32x4 l4 = *(const f32x4*)(sLse + q0 + qt * 16 + g * 4);
-      const f32x4 d4 = *(const f32x4*)(sDel + q0 + qt * 16 + g * 4);
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int qt = 2 * hq + q2;
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float p = fast_exp2(fmaf(s[r], c2, -l4[r]));
-        if (!clean) {
-          const int q = q0 + qt * 16 + g * 4 + r;
-          bool ok = kvalid && q < slen;
-          if (window >= 0) {
-            const int dlt = q - kpos;
-            ok = ok && (dlt <= window) && (dlt >= -window);
-          }
-          p = ok ? p : 0.f;
+        for (int c = 0; c < 2; ++c) {
+          const bf16x8 qfr = *(const bf16x8*)(tQ + v_off(qt * 16 + li, 4 * c + g));
+          const bf16x8 ofr = *(const bf16x8*)(tO + v_off(qt * 16 + li, 4 * c + g));
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[c], s, 0, 0, 0);     // S[q][key]
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[c], dp, 0, 0, 0);   // dP[q][key]
         }
-        pb[qt >> 1][(qt & 1) * 4 + r] = f2bf(p);
-        dsb[qt >> 1][(qt & 1) * 4 + r] = f2bf(p * (dp[r] - d4[r]));
+        const f32x4 l4 = *(const f32x4*)(sLse + q0 + qt * 16 + g * 4);
+        const f32x4 d4 = *(const f32x4*)(sDel + q0 + qt * 16 + g * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = fast_exp2(fmaf(s[r], c2, -l4[r]));
+          if (!clean) {
+            bool ok = (unsigned)(ub + (qt * 16 + r)) <= w2;                  // |q - key| <= window
+            if (!simple) ok = ok && kvalid && (q0 + qt * 16 + g * 4 + r) < slen;
+            p = ok ? p : 0.f;
+          }
+          pb[q2 * 4 + r] = f2bf(p);
+          dsb[q2 * 4 + r] = f2bf(p * (dp[r] - d4[r]));
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(tO, d, hq, lane), pb, dv[d], 0, 0, 0);
+        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(tQ, d, hq, lane), dsb, dk[d], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(tO, d, c, lane), pb[c], dv[d], 0, 0, 0);
-        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(tQ, d, c, lane), dsb[c], dk[d], 0, 0, 0);
-      }
   }
   if (kpos < slen) {
     bf16_t* krow_out = dqkv + (long)(s0 + kpos) * rs + H + head * 64 + g * 4;
@@ -399,51 +455,73 @@ __global__ __launch_bounds__(NT * 256) void attn_bwd_dkv_unit_kernel(
   }
 }
 
-template <int NT>
-constexpr size_t unit_lds() { return 2 * NT * TILE_BYTES + NT * 64 * 8 + 64; }
+constexpr size_t UNIT_LDS = IMG_BYTES + NTMAX * 64 * 8 + 64;
 
-template <typename K>
-void allow_lds(K kern, size_t bytes) {
-  if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+// groups = {n, (seq_begin, nseq, max_len) x n}, every max_len <= 256; longest first
+int build_unit_sched(UnitSched& sc, int& blocks, const int32_t* groups, int heads) {
+  if (groups[0] < 1 || groups[0] > SNX_ATTN_UNIT_GROUPS) return SNX_E_ARG;
+  int order[SNX_ATTN_UNIT_GROUPS];
+  for (int i = 0; i < groups[0]; ++i) order[i] = i;
+  for (int i = 1; i < groups[0]; ++i)
+    for (int j = i; j > 0 && groups[3 + 3 * order[j]] > groups[3 + 3 * order[j - 1]]; --j) {
+      const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp;
+    }
+  sc.n = groups[0];
+  long b = 0;
+  for (int i = 0; i < SNX_ATTN_UNIT_GROUPS; ++i) {
+    sc.seq0[i] = 0; sc.units[i] = 0; sc.ntu[i] = 1;
+    if (i < groups[0]) {
+      const int32_t* e = groups + 1 + 3 * order[i];
+      const int ntu = cdiv(e[2], 64);
+      if (ntu < 1 || ntu > NTMAX || e[1] <= 0) return SNX_E_SHAPE;
+      sc.seq0[i] = e[0]; sc.units[i] = e[1] * heads; sc.ntu[i] = ntu;
+      b += cdiv(sc.units[i], NTMAX / ntu);
+    }
+    if (b > 0x7fffffffL) return SNX_E_SHAPE;
+    sc.bend[i] = (int)b;
+  }
+  blocks = (int)b;
+  return SNX_OK;
+}
+
+void allow_lds(const void* kern) {
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)UNIT_LDS);
 }
 
 }  // namespace
 
-#define UNIT_DISPATCH(NTV, CALL)               \
-  switch (NTV) {                               \
-    case 1: { constexpr int NT = 1; CALL; } break; \
-    case 2: { constexpr int NT = 2; CALL; } break; \
-    case 3: { constexpr int NT = 3; CALL; } break; \
-    case 4: { constexpr int NT = 4; CALL; } break; \
-    default: return SNX_E_SHAPE;               \
-  }
-
-// sequences [seq0, seq0 + nseq) of at most nt * 64 tokens each (nt <= 4)
 int attn_unit_fwd(const bf16_t* qkv, const int32_t* cu_seqlens, const int64_t* mask, bf16_t* out, float* lse, int T,
-                  int heads, int window, int seq0, int nseq, int nt, hipStream_t st) {
-  UNIT_DISPATCH(nt, {
-    auto kern = attn_fwd_unit_kernel<NT>;
-    allow_lds(kern, unit_lds<NT>());
-    hipLaunchKernelGGL(kern, dim3(nseq * heads), dim3(NT * 128), unit_lds<NT>(), st, qkv, cu_seqlens, mask, out, lse, T,
-                       heads, window, 0.125f, seq0);
-  });
+                  int heads, int window, const int32_t* groups, hipStream_t st) {
+  UnitSched sc;
+  int blocks;
+  const int rc = build_unit_sched(sc, blocks, groups, heads);
+  if (rc != SNX_OK) return rc;
+  static bool once = false;
+  if (!once) { allow_lds((const void*)attn_fwd_unit_kernel); once = true; }
+  hipLaunchKernelGGL(attn_fwd_unit_kernel, dim3(blocks), dim3(NTMAX * 128), UNIT_LDS, st, qkv, cu_seqlens, mask, out,
+                     lse, T, heads, window, 0.125f, sc);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }
 
 int attn_unit_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta,
                   const int32_t* cu_seqlens, const int64_t* mask, bf16_t* dqkv, const f32x2* rope_tab,
-                  const int32_t* pos, int T, int heads, int window, int seq0, int nseq, int nt, hipStream_t st) {
-  UNIT_DISPATCH(nt, {
-    auto kq = attn_bwd_dq_unit_kernel<NT>;
-    auto kkv = attn_bwd_dkv_unit_kernel<NT>;
-    allow_lds(kq, unit_lds<NT>());
-    allow_lds(kkv, unit_lds<NT>());
-    hipLaunchKernelGGL(kq, dim3(nseq * heads), dim3(NT * 128), unit_lds<NT>(), st, qkv, out, dout, lse, delta,
-                       cu_seqlens, mask, dqkv, rope_tab, pos, T, heads, window, 0.125f, seq0);
-    hipLaunchKernelGGL(kkv, dim3(nseq * heads), dim3(NT * 256), unit_lds<NT>(), st, qkv, dout, lse, delta, cu_seqlens,
-                       mask, dqkv, rope_tab, pos, T, heads, window, 0.125f, seq0);
-  });
+                  const int32_t* pos, int T, int heads, int window, const int32_t* groups, hipStream_t st) {
+  UnitSched sc;
+  int blocks;
+  const int rc = build_unit_sched(sc, blocks, groups, heads);
+  if (rc != SNX_OK) return rc;
+  static bool once = false;
+  if (!once) {
+    allow_lds((const void*)attn_bwd_dq_unit_kernel);
+    allow_lds((const void*)attn_bwd_dkv_unit_kernel);
+    once = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_dq_unit_kernel, dim3(blocks), dim3(NTMAX * 128), UNIT_LDS, st, qkv, out, dout, lse,
+                     delta, cu_seqlens, mask, dqkv, rope_tab, pos, T, heads, window, 0.125f, sc);
+  SNX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_unit_kernel, dim3(blocks), dim3(NTMAX * 256), UNIT_LDS, st, qkv, dout, lse, delta,
+                     cu_seqlens, mask, dqkv, rope_tab, pos, T, heads, window, 0.125f, sc);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }
