@@ -251,11 +251,15 @@ def geglu_bwd(u: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- attention
-def _check_seqs(cu: torch.Tensor, T: int, max_seqlen: int):
+def _check_seqs(cu: torch.Tensor, T: int, max_seqlen: int, groups=None):
     _chk(cu, torch.int32, "cu_seqlens")
     c = cu.tolist()
     if c[0] != 0 or c[-1] != T or any(b <= a for a, b in zip(c, c[1:])) or max(b - a for a, b in zip(c, c[1:])) > max_seqlen:
         raise ValueError("cu_seqlens must start at 0, end at T, be increasing, with lengths <= max_seqlen")
+    if groups is not None:                       # a group's max_len must cover its sequences (kernels size LDS by it)
+        for s0, n, ml in groups:
+            if s0 < 0 or n <= 0 or s0 + n > len(c) - 1 or max(c[i + 1] - c[i] for i in range(s0, s0 + n)) > ml:
+                raise ValueError("sequence group does not cover its sequences")
 
 
 def attn_fwd(qkv: torch.Tensor, cu: torch.Tensor, mask: torch.Tensor, max_seqlen: int, heads: int,
@@ -269,7 +273,7 @@ def attn_fwd(qkv: torch.Tensor, cu: torch.Tensor, mask: torch.Tensor, max_seqlen
     if mask.numel() != T:
         raise ValueError("attn_fwd: mask must have T elements")
     if validate:
-        _check_seqs(cu, T, max_seqlen)
+        _check_seqs(cu, T, max_seqlen, groups)
     nseq = cu.numel() - 1
     out = torch.empty((T, heads * 64), dtype=BF16, device=qkv.device)
     lse = torch.empty((heads, T), dtype=torch.float32, device=qkv.device)
@@ -293,7 +297,7 @@ def attn_bwd(qkv, out, dout, lse, cu, mask, max_seqlen: int, heads: int, window:
     _chk(out, BF16, "out", (T, heads * 64)); _chk(dout, BF16, "dout", (T, heads * 64))
     _chk(lse, torch.float32, "lse", (heads, T)); _chk(mask, torch.int64, "mask")
     if validate:
-        _check_seqs(cu, T, max_seqlen)
+        _check_seqs(cu, T, max_seqlen, groups)
     nseq = cu.numel() - 1
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((heads, T), dtype=torch.float32, device=qkv.device)

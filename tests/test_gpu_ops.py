@@ -311,7 +311,7 @@ def test_gemm_tn_layout(dev):
     assert torch.equal(dw, x.float()[perm])
 
 
-@pytest.mark.parametrize("S,window", [(64, -1), (256, 64), (200, 8), (130, -1)])
+@pytest.mark.parametrize("S,window", [(64, -1), (256, 64), (200, 8), (130, -1), (320, 64), (300, -1)])
 def test_attention_bwd(dev, S, window):
     from oracle import splade_oracle as O
     ops = _ops()
@@ -490,7 +490,7 @@ def test_attention_sequence_groups_only_size_the_launch(dev, window):
                 [(0, 7, 64), (7, 4, 256)],                      # does not cover all sequences
                 [(0, 14, 300)],                                 # max_len above max_seqlen
                 [(i, 1, 64) for i in range(9)]):                # too many groups
-        with pytest.raises(SnxError):
+        with pytest.raises((SnxError, ValueError)):
             ops.attn_fwd(qkv, cu, mask, 256, heads, window, groups=bad)
 
 
@@ -589,3 +589,28 @@ def test_sparse_topk_rejects_bad_arguments(dev):
         ops.sparse_topk(rep, ok[:50], 5)
     with pytest.raises(ValueError):
         ops.sparse_topk(rep.to(BF16), ok, 5)
+
+
+@pytest.mark.parametrize("window", [-1, 64, 8])
+def test_attention_resident_and_streaming_kernels_agree_bitwise(dev, window):
+    """Sequences of <= 256 tokens take the sequence-resident kernels; declaring the group's max_len > 256 routes the
+    same data through the streaming (tile-by-tile) kernels.  Same math, same accumulation order: identical bits."""
+    ops = _ops()
+    heads = 2
+    lens = [200, 64, 1, 255, 130, 17]
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
+    T = int(cu[-1])
+    g = torch.Generator().manual_seed(77 + window)
+    qkv = (torch.randn(T, 3 * heads * 64, generator=g) * 1.1).to(dev).to(BF16)
+    dout = (torch.randn(T, heads * 64, generator=g) * 0.5).to(dev).to(BF16)
+    mask = torch.ones(T, dtype=torch.int64)
+    mask[5] = 0                                           # a masked key inside the first sequence
+    mask = mask.to(dev)
+    res = [(0, 6, 256)]
+    stream = [(0, 6, 300)]
+    o1, l1 = ops.attn_fwd(qkv, cu, mask, 256, heads, window, groups=res)
+    o2, l2 = ops.attn_fwd(qkv, cu, mask, 300, heads, window, groups=stream)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    d1 = ops.attn_bwd(qkv, o1, dout, l1, cu, mask, 256, heads, window, groups=res)
+    d2 = ops.attn_bwd(qkv, o1, dout, l1, cu, mask, 300, heads, window, groups=stream)
+    assert torch.equal(d1, d2)
