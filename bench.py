@@ -103,8 +103,8 @@ PMC_KERNELS = {
     "gemm_nt_resid": ["gemm_nt_kernel<128, 128, 2, 2, 1>"],
     "gemm_tn_accum": ["gemm_tn_kernel"],
     "decoder_splade_fwd": ["decoder_splade_kernel"],
-    "attn_fwd": ["attn_fwd_kernel"],
-    "attn_bwd": ["attn_bwd_dq_kernel", "attn_bwd_dk"],
+    "attn_fwd": ["attn_fwd_unit_kernel", "attn_fwd_kernel"],
+    "attn_bwd": ["attn_bwd_dq_unit_kernel", "attn_bwd_dkv_unit_kernel", "attn_bwd_dq_kernel", "attn_bwd_dk"],
 }
 
 

@@ -16,6 +16,7 @@ import sys
 
 
 def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)                      # drop the argument list
     m = re.match(r"_Z\d+([A-Za-z_0-9]+?)(ILi[\dELi]+E)?(v|P|i)", name)
     return (m.group(1) + (m.group(2) or "")) if m else name.replace("void ", "").strip()
