@@ -64,7 +64,7 @@ __device__ __forceinline__ bf16x8 stg32_get(const char* w, int row, int chunk) {
   return ((row >> 3) & 1) ? (bf16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]} : v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool MID>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N, int K, int tiles_n, int ntiles,
     EpiArgs e) {
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
       }
     }
   }
-  Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
+  if (MID) Core::template mainloop_mid<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
+  else Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
 
   if (!wide) {                                       // odd widths (tests, tiny heads): direct 8-byte stores
     if (EPI == EPI_STORE_BF16 || EPI == EPI_RESID_F32) {
@@ -241,9 +242,19 @@ static int launch_nt(const void* A, const void* B, int M, int N, int K, const Ep
   constexpr int BM = 128, BN = 128;
   using Core = GemmCore<BM, BN, 2, 2>;
   const int tm = cdiv(M, BM), tn = cdiv(N, BN);
-  auto kern = gemm_nt_kernel<BM, BN, 2, 2, EPI>;
-  hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(Core::NTHREADS), Core::LDS_BYTES, st, (const bf16_t*)A,
-                     (const bf16_t*)B, M, N, K, tn, tm * tn, e);
+  // MID: mid-step barrier main loop (gemm_core.h) -- measured faster for the epilogues that also stream a second
+  // operand (residual, saved u), slower for the plain long-K shapes.  SNX_GEMM_MID=<bitmask over EPI> overrides.
+  static const int mid_mask = getenv("SNX_GEMM_MID") ? atoi(getenv("SNX_GEMM_MID"))
+                                                     : ((1 << EPI_RESID_F32) | (1 << EPI_GEGLU_BWD));
+  if ((mid_mask >> EPI) & 1) {
+    auto kern = gemm_nt_kernel<BM, BN, 2, 2, EPI, true>;
+    hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(Core::NTHREADS), Core::LDS_BYTES, st, (const bf16_t*)A,
+                       (const bf16_t*)B, M, N, K, tn, tm * tn, e);
+  } else {
+    auto kern = gemm_nt_kernel<BM, BN, 2, 2, EPI, false>;
+    hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(Core::NTHREADS), Core::LDS_BYTES, st, (const bf16_t*)A,
+                       (const bf16_t*)B, M, N, K, tn, tm * tn, e);
+  }
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }

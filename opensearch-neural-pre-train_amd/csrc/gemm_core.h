@@ -125,6 +125,72 @@ struct GemmCore {
     }
   }
 
+  // Variant with a mid-step barrier: once every wave holds the fragments of K-tile kt in registers, the
+  // stage they came from is refilled at once with tile kt+2, so a DMA has 1.5 K-steps to land instead of 1
+  // (counted vmcnt: the newest tile stays in flight across the step boundary).
+  template <bool TRANSPOSED = false>
+  static __device__ __forceinline__ void mainloop_mid(const bf16_t* __restrict__ A, long lda, int m0, int M,
+                                                      const bf16_t* __restrict__ B, long ldb, int n0, int N,
+                                                      int K, char* smem, f32x4 (&acc)[MI][NI]) {
+    static_assert((BM / 8 / NW) + (BN / 8 / NW) == 8, "vmcnt(8) below = the DMA instructions of one K-tile per wave");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int nk = K / BK;
+    stage<BM>(A, lda, m0, M, 0, smem, wave, lane);
+    stage<BN>(B, ldb, n0, N, 0, smem + A_BYTES, wave, lane);
+    if (nk > 1) {
+      stage<BM>(A, lda, m0, M, BK, smem + STAGE_BYTES, wave, lane);
+      stage<BN>(B, ldb, n0, N, BK, smem + STAGE_BYTES + A_BYTES, wave, lane);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                  // tile kt landed for every wave
+      char* cur = smem + (kt & 1) * STAGE_BYTES;
+      const char* ta = cur;
+      const char* tb = cur + A_BYTES;
+      bf16x8 a[2][MI], b[2][NI];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = kk * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[kk][i] = frag(ta, wm * WTM + i * 16 + (lane & 15), chunk);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[kk][j] = frag(tb, wn * WTN + j * 16 + (lane & 15), chunk);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = TRANSPOSED ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0][j], a[0][i], acc[i][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+      // first (MI+NI) reads before the first MFMA, the other (MI+NI) reads paired with MFMAs
+#pragma unroll
+      for (int q = 0; q < MI + NI; ++q) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+      for (int q = 0; q < MI + NI; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - (MI + NI), 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                  // every wave has its fragments: the stage is free
+      if (kt + 2 < nk) {
+        stage<BM>(A, lda, m0, M, (kt + 2) * BK, cur, wave, lane);
+        stage<BN>(B, ldb, n0, N, (kt + 2) * BK, cur + A_BYTES, wave, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = TRANSPOSED ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][j], a[1][i], acc[i][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+    }
+  }
+
   // Accumulator element (i, j, r) of this lane is C[row][col] with
   //   row = m0 + wm*WTM + i*16 + (lane>>4)*4 + r,   col = n0 + wn*WTN + j*16 + (lane&15).
   static __device__ __forceinline__ int acc_row(int i, int r) {
