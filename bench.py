@@ -98,9 +98,9 @@ def cpu_baseline(seconds_budget: float = 30.0):
 
 # kernel names (as rocprofv3 reports them) behind each profiler class, for the PMC traffic lookup
 PMC_KERNELS = {
-    "gemm_nt_bf16": ["gemm_nt_kernel<128, 128, 2, 2, 0>", "gemm_nt_kernel<128, 128, 2, 2, 2>",
-                     "gemm_nt_kernel<128, 128, 2, 2, 3>", "gemm_nt_kernel<128, 128, 2, 2, 4>"],
-    "gemm_nt_resid": ["gemm_nt_kernel<128, 128, 2, 2, 1>"],
+    "gemm_nt_bf16": ["gemm_nt_kernel<128, 128, 2, 2, 0", "gemm_nt_kernel<128, 128, 2, 2, 2",
+                     "gemm_nt_kernel<128, 128, 2, 2, 3", "gemm_nt_kernel<128, 128, 2, 2, 4"],
+    "gemm_nt_resid": ["gemm_nt_kernel<128, 128, 2, 2, 1"],
     "gemm_tn_accum": ["gemm_tn_kernel"],
     "decoder_splade_fwd": ["decoder_splade_kernel"],
     "attn_fwd": ["attn_fwd_unit_kernel", "attn_fwd_kernel"],
