@@ -348,13 +348,13 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_bwd_dq_unit_kernel(
 }
 
 // ------------------------------------------------------------------------------------ backward dK, dV
-__global__ __launch_bounds__(NTMAX * 256) void attn_bwd_dkv_unit_kernel(
+__global__ __launch_bounds__(NTMAX * 128, 4) void attn_bwd_dkv_unit_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, const int32_t* __restrict__ cu_seqlens, const int64_t* __restrict__ mask,
     bf16_t* __restrict__ dqkv, const f32x2* __restrict__ rope_tab, const int32_t* __restrict__ pos, int T,
     int heads, int window, float scale, const UnitSched sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const Slot t = slot_of_block<1>(sched, cu_seqlens, heads);
+  const Slot t = slot_of_block<2>(sched, cu_seqlens, heads);
   const int ntu = t.ntu;
   char* sQ = smem + t.slot * 2 * ntu * TILE_BYTES;
   char* sO = sQ + ntu * TILE_BYTES;
@@ -367,8 +367,8 @@ __global__ __launch_bounds__(NTMAX * 256) void attn_bwd_dkv_unit_kernel(
   const long rs = 3L * H;
   const bf16_t* qbase = qkv + (long)s0 * rs + head * 64;
   if (t.live) {
-    load_image<1>(qbase, rs, t, sQ);
-    load_image<1>(dout + (long)s0 * H + head * 64, H, t, sO);
+    load_image<2>(qbase, rs, t, sQ);
+    load_image<2>(dout + (long)s0 * H + head * 64, H, t, sO);
     if (t.lt < ntu * 64) {
       const int qc = t.lt < slen ? t.lt : slen - 1;
       sLse[t.lt] = lse[(long)head * T + s0 + qc] * LOG2E;       // log2 domain
@@ -377,7 +377,8 @@ __global__ __launch_bounds__(NTMAX * 256) void attn_bwd_dkv_unit_kernel(
   }
   __syncthreads();
   if (!t.live) return;
-  for (int rg = t.lw; rg < ntu * 4; rg += t.wpu) {          // one 16-row group per wave (register budget)
+#pragma unroll 1
+  for (int rg = t.lw; rg < ntu * 4; rg += t.wpu) {          // this wave's 16-row groups
   const int row_lo = rg * 16;
   if (row_lo >= slen) break;
   const int kpos = row_lo + li;
@@ -520,7 +521,7 @@ int attn_unit_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, cons
   hipLaunchKernelGGL(attn_bwd_dq_unit_kernel, dim3(blocks), dim3(NTMAX * 128), UNIT_LDS, st, qkv, out, dout, lse,
                      delta, cu_seqlens, mask, dqkv, rope_tab, pos, T, heads, window, 0.125f, sc);
   SNX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_dkv_unit_kernel, dim3(blocks), dim3(NTMAX * 256), UNIT_LDS, st, qkv, dout, lse, delta,
+  hipLaunchKernelGGL(attn_bwd_dkv_unit_kernel, dim3(blocks), dim3(NTMAX * 128), UNIT_LDS, st, qkv, dout, lse, delta,
                      cu_seqlens, mask, dqkv, rope_tab, pos, T, heads, window, 0.125f, sc);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
