@@ -135,6 +135,7 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_fwd_unit_kernel(const bf1
   }
   __syncthreads();
   if (!t.live) return;
+#pragma unroll 1
   for (int rg = t.lw; rg < ntu * 4; rg += t.wpu) {          // this wave's 16-row groups
   const int row_lo = rg * 16;
   if (row_lo >= slen) break;
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_bwd_dq_unit_kernel(
   }
   __syncthreads();
   if (!t.live) return;
+#pragma unroll 1
   for (int rg = t.lw; rg < ntu * 4; rg += t.wpu) {          // this wave's 16-row groups
   const int row_lo = rg * 16;
   if (row_lo >= slen) break;
