@@ -10,8 +10,12 @@
  * Conventions (all entry points):
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host];
  *   - caller owns all buffers; nothing is allocated, freed or synchronised inside;
- *   - work is enqueued on `stream` and is ordered with other work on that stream; re-entrant
- *     across streams (no hidden global state), hipGraph-capturable;
+ *   - work is enqueued on `stream` and is ordered with other work on that stream; the operator entry
+ *     points are re-entrant across streams (no hidden state).  snx_model_backward additionally forks its
+ *     weight-gradient GEMMs onto ONE process-wide internal stream (event fork/join, joined before it
+ *     returns: callers still see everything ordered on `stream`); it is therefore not meant to be called
+ *     from several host threads at once (one process drives one GPU).  SNX_BWD_OVERLAP=0 keeps everything
+ *     on `stream`;
  *   - return 0 on success, a positive hipError_t if a launch failed, or a negative SNX_E_* code
  *     when the arguments violate a kernel's shape assumptions (checked on the host BEFORE any
  *     launch -- a mis-shaped call never reaches the GPU);
