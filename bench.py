@@ -54,16 +54,21 @@ def synth_ids(B, S, vocab, pad, gen, dev):
     return ids.to(dev), torch.ones(B, S, dtype=torch.int64, device=dev)
 
 
-def make_batches(n, B, Sq, Sd, k, vocab, pad, seed, dev):
+def make_batches(n, B, Sq, Sd, k, vocab, pad, seed, dev, teacher=False):
     gen = torch.Generator().manual_seed(seed)
     out = []
     for _ in range(n):
         q, qm = synth_ids(B, Sq, vocab, pad, gen, dev)
         p, pm = synth_ids(B, Sd, vocab, pad, gen, dev)
         n_, nm = synth_ids(B * k, Sd, vocab, pad, gen, dev)
-        out.append({"query_input_ids": q, "query_attention_mask": qm, "positive_input_ids": p,
-                    "positive_attention_mask": pm, "negative_input_ids": n_, "negative_attention_mask": nm,
-                    "num_negatives": k})
+        b = {"query_input_ids": q, "query_attention_mask": qm, "positive_input_ids": p,
+             "positive_attention_mask": pm, "negative_input_ids": n_, "negative_attention_mask": nm,
+             "num_negatives": k}
+        if teacher:                                  # pos ~ U(0.5, 1), neg ~ U(0, 0.6)
+            b["teacher_pos_scores"] = (0.5 + 0.5 * torch.rand(B, generator=gen)).to(dev)
+            tn = 0.6 * torch.rand(B, k, generator=gen)
+            b["teacher_neg_scores"] = (tn if k > 1 else tn[:, 0]).to(dev)
+        out.append(b)
     return out
 
 
@@ -108,21 +113,45 @@ PMC_KERNELS = {
 }
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h): the PMC file records the hash it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "opensearch-neural-pre-train_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+
+
 def pmc_traffic(cls: str):
-    """Average fabric bytes per launch of the class's kernels, from the committed counter passes
-    (tools/pmc_traffic.py); None when the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    """(average fabric bytes per launch of the class's kernels, provenance) from the committed counter passes
+    (tools/pmc_traffic.py).  The counters cannot be collected inside a timed run, so the figure is only
+    reported when the file was measured on EXACTLY the kernel sources being benchmarked (source hash
+    recorded in the file); otherwise traffic is null."""
+    path = os.path.join(ROOT, PMC_FILE)
     try:
         with open(path) as fh:
-            kernels = json.load(fh)["kernels"]
+            doc = json.load(fh)
+        kernels = doc["kernels"]
     except (OSError, KeyError, ValueError):
-        return None
+        return None, {"file": PMC_FILE, "status": "absent"}
+    prov = {"file": PMC_FILE, "kernel_source_sha256": doc.get("kernel_source_sha256"),
+            "workload": doc.get("workload")}
+    if doc.get("kernel_source_sha256") != kernel_source_hash():
+        prov["status"] = "stale: kernel sources changed since the counter passes; traffic withheld"
+        return None, prov
     tot = n = 0.0
     for name, rec in kernels.items():
         if any(name.startswith(k) for k in PMC_KERNELS.get(cls, [])):
             tot += rec["fabric_bytes_per_launch"] * rec["launches"]
             n += rec["launches"]
-    return tot / n if n else None
+    prov["status"] = "current"
+    return (tot / n if n else None), prov
 
 
 def main():
@@ -135,6 +164,7 @@ def main():
     ap.add_argument("--d-len", type=int, default=256)
     ap.add_argument("--negatives", type=int, default=1)
     ap.add_argument("--accum", type=int, default=4)
+    ap.add_argument("--margin-mse", type=float, default=0.0, help="lambda_margin_mse (v34 configs: 0.5)")
     ap.add_argument("--cross-gpu-negatives", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -168,18 +198,21 @@ def main():
     wrapped = T.NativeDataParallel(model)
     loss_fn = SPLADELossV33(lambda_q=config.loss.lambda_q, lambda_d=config.loss.lambda_d,
                             temperature=config.loss.temperature, flops_warmup_steps=config.loss.flops_warmup_steps,
-                            lambda_initial_ratio=config.loss.lambda_initial_ratio).to(dev)
+                            lambda_initial_ratio=config.loss.lambda_initial_ratio,
+                            lambda_margin_mse=args.margin_mse).to(dev)
     optimizer = T.build_optimizer(wrapped, config)
     scheduler = T.build_scheduler(optimizer, 100, 10000)
     B, Sq, Sd, k = args.batch, args.q_len, args.d_len, args.negatives
     n_batches = min(args.steps + args.warmup, 8)
-    batches = make_batches(n_batches, B, Sq, Sd, k, model.vocab_size, model.config.pad_token_id, 42 + rank, dev)
+    batches = make_batches(n_batches, B, Sq, Sd, k, model.vocab_size, model.config.pad_token_id, 42 + rank, dev,
+                           teacher=args.margin_mse > 0)
     xneg = args.cross_gpu_negatives
     state = {"i": 0, "gs": 0}
 
     def one_step():
         b = batches[state["i"] % n_batches]
-        loss, _ = T.micro_step(wrapped, loss_fn, b, state["gs"], dev, args.accum, xneg)
+        loss, _ = T.micro_step(wrapped, loss_fn, b, state["gs"], dev, args.accum, xneg,
+                               last_of_window=(state["i"] + 1) % args.accum == 0)
         state["i"] += 1
         if state["i"] % args.accum == 0:
             T.optimizer_step(wrapped, optimizer, scheduler, config)
@@ -209,13 +242,17 @@ def main():
     fl = flops_per_triplet(Sq, Sd, k)
     triplets_per_s = args.steps * B * world / dt
     result = {
-        "metric": "triplets/sec (q64/d256, bs=64/GPU)", "value": triplets_per_s, "unit": "triplets/s",
+        "metric": f"triplets/sec (q{Sq}/d{Sd}, bs={B}/GPU)", "value": triplets_per_s, "unit": "triplets/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"SPLADEModernBERT 149M (A.X-Encoder-base geometry, random init) DDP step: "
                                f"bs={B}/GPU, q{Sq}/d{Sd}, {k} neg, InfoNCE+FLOPS, grad-accum {args.accum}, "
                                f"AdamW+clip every {args.accum} micro-steps"
-                               + (", cross-GPU in-batch negatives" if xneg else ""),
+                               + (", MarginMSE 0.5 with synthetic teacher scores" if args.margin_mse > 0 else "")
+                               + (", cross-GPU in-batch negatives" if xneg else "")
+                               + "; 8 pre-staged device batches cycled through ddp_trainer.micro_step / "
+                                 "optimizer_step (the body of train_epoch); no per-micro-step loss.item() "
+                                 "(ref:train_v33_ddp.py:444 has one): the loss stays on the device",
                    "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": final_loss},
         "mfma_roofline_frac_step": triplets_per_s * fl["step"] / (world * PEAK_BF16_TFLOPS * 1e12),
         "mfma_roofline_frac_executed": triplets_per_s * fl["step_executed"] / (world * PEAK_BF16_TFLOPS * 1e12),
@@ -242,15 +279,17 @@ def main():
         mfma = {"gemm_nt_bf16", "gemm_nt_resid", "gemm_tn_accum", "decoder_splade_fwd", "attn_fwd", "attn_bwd"}
         dom = max((c for c in classes if c in mfma), key=lambda c: classes[c]["ms_per_step"])
         ach = classes[dom]["work_per_s"] / 1e12
+        traffic, prov = pmc_traffic(dom)
         result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-                              "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom),
+                              "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                              "traffic_provenance": prov,
                               "avg_launch_us": classes[dom]["avg_us"],
                               "note": "algorithmic FLOPs of every launch of this kernel class in a step / summed "
                                       "HIP-event durations of those launches (rank 0; accum extra steps right after "
                                       "the timed region, with the backward's side stream folded into the launch "
                                       "stream so that kernels are timed one at a time); traffic = fabric bytes per "
-                                      "launch from the committed PMC passes (profiles/r01_pmc_traffic.json: "
-                                      "2 x FETCH_SIZE + WRITE_SIZE, averaged over this class's kernels)"}
+                                      "launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, averaged "
+                                      "over this class's kernels), null unless measured on these kernel sources"}
         result["kernel_classes"] = classes
     elif world > 1 and not args.no_profile:
         for _ in range(args.accum):     # keep collectives matched with rank 0's profiled steps

@@ -99,6 +99,22 @@ int snx_model_backward(const snx_model_desc* d, const void* const* params /*[hos
                        const float* g_sparse, void* scratch, const int32_t* groups /*[host] or NULL, as forward*/,
                        int32_t T, int32_t nseq, int32_t max_seqlen, hipStream_t stream);
 
+/* The same backward as a chain of layers + 2 UNITS in execution order: unit 0 = SPLADE tail + tied decoder +
+ * head + final norm, unit 1 + i = encoder layer (layers - 1 - i), unit layers + 1 = embeddings.  Consecutive
+ * calls over [unit_begin, unit_end) ranges that together cover [0, layers + 2), with the SAME scratch buffer,
+ * equal one snx_model_backward.  When a range returns, the gradients of its parameters are complete (except
+ * the tied embedding matrix, which receives the decoder's share in unit 0 and the embedding's in the last):
+ * `notify` (nullable) is made to wait for them (launch stream AND the internal weight-gradient stream), so
+ * that a data-parallel caller can all-reduce that slice there while later units still run -- the overlap the
+ * reference gets from DDP's bucketed reducer (ref:src/train/cli/train_v33_ddp.py:539-544,363-364). */
+int snx_model_backward_units(const snx_model_desc* d, const void* const* params /*[host]*/,
+                             void* const* grads /*[host]*/, const void* wcache, const int64_t* ids,
+                             const int64_t* mask, const int32_t* cu_seqlens, const int32_t* pos,
+                             const float* rope_global, const float* rope_local, const void* saved,
+                             const float* g_sparse, void* scratch, const int32_t* groups /*[host] or NULL*/,
+                             int32_t T, int32_t nseq, int32_t max_seqlen, int32_t unit_begin, int32_t unit_end,
+                             hipStream_t notify, hipStream_t stream);
+
 /* ---- inference post-processing (ref:benchmark/encoders.py:309-345 NeuralSparseEncoderV33._encode_batch) ---- */
 /* Per row of rep [B,V] fp32: entries with rep > 0 and allowed[v] != 0 survive.  k > 0 and more than k survivors:
  * the k largest, weight descending, ties lowest id first (out_sorted[b] = 1); otherwise all survivors in id

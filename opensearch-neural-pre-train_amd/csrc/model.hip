@@ -187,6 +187,7 @@ struct Side {
   std::vector<hipEvent_t> ev;
   size_t next = 0;
   int enabled = -1;
+  hipEvent_t read_a = nullptr, read_du = nullptr, read_dqkv = nullptr;
   bool on() {
     if (enabled < 0) {
       const char* e = getenv("SNX_BWD_OVERLAP");
@@ -204,6 +205,24 @@ struct Side {
     return ev[next++];
   }
 } g_side;
+
+// unmasked (query, key) pairs of one attention layer over the call's sequence groups (group maximum lengths:
+// exact for dense batches, an upper bound for ragged ones); window < 0 = global layer
+double attn_pairs(const int32_t* groups, int nseq, int max_seqlen, int window) {
+  int32_t one[4] = {1, 0, nseq, max_seqlen};
+  const int32_t* g = groups ? groups : one;
+  double tot = 0;
+  for (int i = 0; i < g[0]; ++i) {
+    const double ns = g[2 + 3 * i], S = g[3 + 3 * i];
+    double per = S * S;
+    if (window >= 0 && 2 * window + 1 < S) {     // band |i-j| <= w clipped at both ends
+      const double w = window;
+      per = S * (2 * w + 1) - w * (w + 1);
+    }
+    tot += ns * per;
+  }
+  return tot;
+}
 
 #define RC(call)            \
   do {                      \
@@ -297,7 +316,7 @@ extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* par
     { PROF(PC_GEMM_NT, 2.0 * T * 3 * H * H);      // Wqkv + RoPE fused
       RC(snx_gemm_nt_rope(sv + s.x_attn[l], wc + c.wqkv[l], sv + s.qkv[l], global ? rope_global : rope_local, pos,
                           2 * H, T, 3 * H, H, st)); }
-    { PROF(PC_ATTN_FWD, 4.0 * TH * (global ? max_seqlen : (2 * d->window + 1 < max_seqlen ? 2 * d->window + 1 : max_seqlen)));
+    { PROF(PC_ATTN_FWD, 4.0 * H * attn_pairs(groups, nseq, max_seqlen, global ? -1 : d->window));
       RC(snx_attn_fwd_ex(sv + s.qkv[l], cu_seqlens, mask, sv + s.attn[l], (float*)(sv + s.lse[l]), groups, T, nseq,
                          max_seqlen, d->heads, d->head_dim, global ? -1 : d->window, st)); }
     { PROF(PC_GEMM_NT_RESID, 2.0 * TH * H); RC(snx_gemm_nt_resid(sv + s.attn[l], wc + c.wo[l], hbuf(2 * l), hbuf(2 * l + 1), T, H, H, st)); }
@@ -326,16 +345,22 @@ extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* par
   return SNX_OK;
 }
 
-extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* params, void* const* grads,
-                                  const void* wcache, const int64_t* ids, const int64_t* mask,
-                                  const int32_t* cu_seqlens, const int32_t* pos, const float* rope_global,
-                                  const float* rope_local, const void* saved, const float* g_sparse, void* scratch,
-                                  const int32_t* groups, int32_t T, int32_t nseq, int32_t max_seqlen,
-                                  hipStream_t st) {
+// The backward is a chain of L + 2 UNITS in execution order: unit 0 = SPLADE tail + decoder + head + final norm,
+// unit 1 + i = encoder layer L-1-i, unit L + 1 = embeddings.  A caller may run it in several calls over
+// consecutive unit ranges (same scratch buffer): the parameter gradients of a finished range are final, so a
+// data-parallel trainer can all-reduce them on `notify` while the remaining units still run.
+extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* const* params, void* const* grads,
+                                        const void* wcache, const int64_t* ids, const int64_t* mask,
+                                        const int32_t* cu_seqlens, const int32_t* pos, const float* rope_global,
+                                        const float* rope_local, const void* saved, const float* g_sparse,
+                                        void* scratch, const int32_t* groups, int32_t T, int32_t nseq,
+                                        int32_t max_seqlen, int32_t unit_begin, int32_t unit_end, hipStream_t notify,
+                                        hipStream_t st) {
   if (!desc_ok(d)) return SNX_E_SHAPE;
   if (!params || !grads || !wcache || !ids || !mask || !cu_seqlens || !pos || !rope_global || !rope_local || !saved ||
       !g_sparse || !scratch || T <= 0 || nseq <= 0 || max_seqlen <= 0)
     return SNX_E_ARG;
+  if (unit_begin < 0 || unit_end > d->layers + 2 || unit_begin >= unit_end) return SNX_E_ARG;
   CachePlan c;
   SavedPlan s;
   BwdPlan b;
@@ -356,7 +381,10 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
   // dW GEMMs go to the side stream unless the per-class profiler is timing kernels one by one
   const bool overlap = !g_prof.on && g_side.on();
   hipStream_t ss = overlap ? g_side.s : st;
-  g_side.next = 0;
+  if (unit_begin == 0) {                              // a new backward: recycle the event pool
+    g_side.next = 0;
+    g_side.read_a = g_side.read_du = g_side.read_dqkv = nullptr;
+  }
   auto fork = [&]() -> int {                          // side stream: wait for everything enqueued on st so far
     if (!overlap) return SNX_OK;
     hipEvent_t e = g_side.get();
@@ -372,22 +400,27 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
     if (!overlap || !e) return SNX_OK;
     return hipStreamWaitEvent(st, e, 0) == hipSuccess ? SNX_OK : SNX_E_ARG;
   };
-  hipEvent_t read_a = nullptr, read_du = nullptr, read_dqkv = nullptr;   // last side-stream reader of A / Wd / Wq
+  // last side-stream reader of A / Wd / Wq (kept across the calls of one backward)
+  hipEvent_t &read_a = g_side.read_a, &read_du = g_side.read_du, &read_dqkv = g_side.read_dqkv;
 
   const double TH = (double)T * H;
-  // SPLADE tail + decoder (sparse routed), head
-  { PROF(PC_SPLADE_BWD, 2.0 * 2.0 * nseq * V * H);
-    RC(snx_splade_bwd(g_sparse, (const uint32_t*)(sv + s.keys), sv + s.hd, wc + c.emb, cu_seqlens, A, G(p.tok_emb()),
-                      G(p.dec_bias()), sc + b.splade, T, nseq, max_seqlen, V, H, st)); }
-  { PROF(PC_LN_BWD, TH * 6); RC(snx_gelu_ln_bwd(A, sv + s.dd, F(p.head_norm()), Bb, G(p.head_norm()), T, H, d->ln_eps, st)); }
-  { PROF(PC_GEMM_TN, 2.0 * TH * H); RC(snx_gemm_tn_accum(Bb, sv + s.xf, G(p.head_dense()), T, H, H, st)); }
-  { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(Bb, wc + c.dense_t, A, T, H, H, st)); }
-  // every LayerNorm backward also emits bf16(dh) into A: the gradient of the next bf16 branch output
-  { PROF(PC_LN_BWD, TH * 12); RC(snx_ln_bwd(A, hbuf(2 * L), F(p.final_norm()), dh, A, G(p.final_norm()), T, H, d->ln_eps, 1, st)); }
+  if (unit_begin == 0) {
+    // SPLADE tail + decoder (sparse routed), head
+    { PROF(PC_SPLADE_BWD, 2.0 * 2.0 * nseq * V * H);
+      RC(snx_splade_bwd(g_sparse, (const uint32_t*)(sv + s.keys), sv + s.hd, wc + c.emb, cu_seqlens, A, G(p.tok_emb()),
+                        G(p.dec_bias()), sc + b.splade, T, nseq, max_seqlen, V, H, st)); }
+    { PROF(PC_LN_BWD, TH * 6); RC(snx_gelu_ln_bwd(A, sv + s.dd, F(p.head_norm()), Bb, G(p.head_norm()), T, H, d->ln_eps, st)); }
+    { PROF(PC_GEMM_TN, 2.0 * TH * H); RC(snx_gemm_tn_accum(Bb, sv + s.xf, G(p.head_dense()), T, H, H, st)); }
+    { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(Bb, wc + c.dense_t, A, T, H, H, st)); }
+    // every LayerNorm backward also emits bf16(dh) into A: the gradient of the next bf16 branch output
+    { PROF(PC_LN_BWD, TH * 12); RC(snx_ln_bwd(A, hbuf(2 * L), F(p.final_norm()), dh, A, G(p.final_norm()), T, H, d->ln_eps, 1, st)); }
+  }
 
-  for (int l = L - 1; l >= 0; --l) {
+  const int l_hi = L - 1 - (unit_begin > 1 ? unit_begin - 1 : 0);
+  const int l_lo = L - 1 - ((unit_end < L + 1 ? unit_end : L + 1) - 2);
+  for (int l = l_hi; l >= l_lo && l >= 0; --l) {
     const bool global = (l % d->global_every) == 0;
-    const double attn_keys = global ? max_seqlen : (2 * d->window + 1 < max_seqlen ? 2 * d->window + 1 : max_seqlen);
+    const double pairs = attn_pairs(groups, nseq, max_seqlen, global ? -1 : d->window);
     // ---- MLP:  h[2l+2] = h[2l+1] + Wo( gelu(a) * g ),  [a|g] = Wi( LN(h[2l+1]) )
     RC(fork());
     { ProfScope ps(PC_GEMM_TN, 2.0 * TH * I, ss); RC(snx_gemm_tn_accum(A, sv + s.y[l], G(p.wo_mlp(l)), T, H, I, ss)); }
@@ -407,7 +440,7 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
     RC(mark(read_a));
     { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(A, wc + c.wo_t[l], Bb, T, H, H, st)); }    // d(attn out)
     RC(join(read_dqkv));                           // previous layer's dWqkv has finished reading dqkv
-    { PROF(PC_ATTN_BWD, 10.0 * TH * attn_keys);
+    { PROF(PC_ATTN_BWD, 10.0 * H * pairs);
       RC(snx_attn_bwd_ex(sv + s.qkv[l], sv + s.attn[l], Bb, (const float*)(sv + s.lse[l]), cu_seqlens, mask,
                          (float*)(sc + b.delta), Wq, global ? rope_global : rope_local, pos, groups, T, nseq,
                          max_seqlen, d->heads, d->head_dim, global ? -1 : d->window, st)); }      // inverse RoPE fused
@@ -425,11 +458,34 @@ extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* pa
       SNX_CHECK_LAUNCH();
     }
   }
-  RC(join(read_dqkv));                             // the side stream is in order: its last mark covers all of it
-  { PROF(PC_EMBED, TH * 12);
-    RC(snx_embed_ln_bwd(dh, ids, F(p.tok_emb()), F(p.emb_norm()), G(p.tok_emb()), G(p.emb_norm()), T, H, d->ln_eps,
-                        d->pad_id, st)); }
+  if (unit_end == L + 2) {
+    RC(join(read_dqkv));                           // the side stream is in order: its last mark covers all of it
+    { PROF(PC_EMBED, TH * 12);
+      RC(snx_embed_ln_bwd(dh, ids, F(p.tok_emb()), F(p.emb_norm()), G(p.tok_emb()), G(p.emb_norm()), T, H, d->ln_eps,
+                          d->pad_id, st)); }
+  }
+  if (notify) {
+    // `notify` learns that every gradient written by units [unit_begin, unit_end) is complete: it waits for
+    // this point of the launch stream and of the weight-gradient side stream (the caller's stream does not)
+    hipEvent_t e = g_side.get();
+    if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(notify, e, 0) != hipSuccess) return SNX_E_ARG;
+    if (overlap) {
+      hipEvent_t e2 = g_side.get();
+      if (!e2 || hipEventRecord(e2, ss) != hipSuccess || hipStreamWaitEvent(notify, e2, 0) != hipSuccess) return SNX_E_ARG;
+    }
+  }
   return SNX_OK;
+}
+
+extern "C" int snx_model_backward(const snx_model_desc* d, const void* const* params, void* const* grads,
+                                  const void* wcache, const int64_t* ids, const int64_t* mask,
+                                  const int32_t* cu_seqlens, const int32_t* pos, const float* rope_global,
+                                  const float* rope_local, const void* saved, const float* g_sparse, void* scratch,
+                                  const int32_t* groups, int32_t T, int32_t nseq, int32_t max_seqlen,
+                                  hipStream_t st) {
+  if (!desc_ok(d)) return SNX_E_SHAPE;
+  return snx_model_backward_units(d, params, grads, wcache, ids, mask, cu_seqlens, pos, rope_global, rope_local, saved,
+                                  g_sparse, scratch, groups, T, nseq, max_seqlen, 0, d->layers + 2, nullptr, st);
 }
 
 // ---- profiling API (see ProfScope above) ---------------------------------------------------

@@ -6,8 +6,11 @@ autograd graph boundary.  All arithmetic happens in libsnx.so."""
 from __future__ import annotations
 
 import ctypes as C
+import logging
+import os
+from collections import OrderedDict
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -15,6 +18,8 @@ from ._lib import check, fn
 from .ops import _p, _stream, rope_table
 
 SNX_FWD_SAVE_FOR_BACKWARD = 1
+_SEQ_CACHE_ENTRIES = 64
+logger = logging.getLogger(__name__)
 
 
 class ModelDesc(C.Structure):
@@ -71,10 +76,17 @@ class EncoderRuntime:
         self._wcache: Optional[torch.Tensor] = None
         self._wcache_key = None
         self._rope: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
-        self._seq_cache: Dict[Tuple[int, int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._seq_cache: "OrderedDict[tuple, tuple]" = OrderedDict()   # LRU, bounded (dynamic padding)
         self.direct_grads = False
         self.flat_grad: Optional[torch.Tensor] = None
         self.flat_param: Optional[torch.Tensor] = None
+        # parity tests read the routing of the latest forward from here; off by default because it would
+        # keep the multi-GB activation arena alive until the next forward (SNX_KEEP_LAST_CTX=1 or set it)
+        self.keep_last_ctx = os.environ.get("SNX_KEEP_LAST_CTX", "0") == "1"
+        self.last_ctx = None
+        # bucketed gradient exchange overlapped with the backward (snx.dist.BucketedGradSync); armed per call
+        self.grad_sync = None
+        self._warned_autocast = False
 
     # ------------------------------------------------------------------ parameter plumbing
     def _device(self):
@@ -83,6 +95,45 @@ class EncoderRuntime:
             raise RuntimeError("SPLADEModernBERT (snx backend) runs on an AMD GPU only: move the module to "
                                "cuda:<local_rank>; there is no CPU fallback for the product path")
         return d
+
+    def param_offsets(self) -> List[int]:
+        """Element offset of every parameter in the flat (canonical-order) gradient / parameter buffers."""
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += p.numel()
+        return offs + [off]
+
+    def unit_param_range(self, unit_begin: int, unit_end: int) -> List[Tuple[int, int]]:
+        """Flat element ranges whose gradients are COMPLETE once backward units [unit_begin, unit_end) have run
+        (include/snx.h snx_model_backward_units: unit 0 = tail, 1 + i = layer L-1-i, L + 1 = embeddings)."""
+        L = self.geom.num_hidden_layers
+        offs = self.param_offsets()
+        first = lambda l: 2 if l == 0 else 7 + 6 * (l - 1)   # noqa: E731  index of the layer's first parameter
+        tail = 7 + 6 * (L - 1)
+        out = []
+        if unit_begin == 0:
+            out.append((offs[tail], offs[tail + 4]))
+        lo_unit, hi_unit = max(unit_begin, 1), min(unit_end, L + 1)
+        if lo_unit < hi_unit:
+            l_hi, l_lo = L - lo_unit, L + 1 - hi_unit
+            begin = offs[first(l_lo)]
+            end = offs[tail] if l_hi == L - 1 else offs[first(l_hi + 1)]
+            if unit_end == L + 2 and l_lo == 0:
+                begin = 0                                   # embeddings + their norm sit right below layer 0
+            out.append((begin, end))
+        elif unit_end == L + 2:
+            out.append((0, offs[2]))
+        if unit_end == L + 2 and lo_unit < hi_unit and L + 1 - hi_unit != 0:
+            out.append((0, offs[2]))
+        out.sort()
+        merged = [out[0]]
+        for lo, hi in out[1:]:                              # adjacent slices -> one collective
+            if lo == merged[-1][1]:
+                merged[-1] = (merged[-1][0], hi)
+            else:
+                merged.append((lo, hi))
+        return merged
 
     def _param_ptrs(self):
         key = tuple(p.data_ptr() for p in self.params)
@@ -175,6 +226,13 @@ class EncoderRuntime:
         -- only the valid tokens are gathered and computed (the kernels take cu_seqlens); the
         lengths come from the host-side collator output, so no device sync is needed."""
         dev = self._device()
+        if not self._warned_autocast and not (torch.is_autocast_enabled("cuda")
+                                              and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            self._warned_autocast = True
+            logger.warning("SPLADEModernBERT (snx backend) always computes with the bf16 cast points of the reference's "
+                           "training path (autocast(cuda, bf16), ref:train_v33_ddp.py:337); it was called outside bf16 "
+                           "autocast, where the reference would compute in fp32 -- expect |delta| ~1e-2 on sparse weights "
+                           "(see INTEGRATION.md, 'precision outside autocast')")
         shapes = []
         for ids, mask in pairs:
             if ids.dim() != 2 or mask.shape != ids.shape:
@@ -221,6 +279,8 @@ class EncoderRuntime:
         else:
             key = (tuple(shapes), str(dev))
             lay = self._seq_cache.get(key)
+            if lay is not None:
+                self._seq_cache.move_to_end(key)
             if lay is None:
                 cu, pos, groups, t0, s0 = [0], [], [len(shapes)], 0, 0
                 for B, S in shapes:
@@ -232,19 +292,22 @@ class EncoderRuntime:
                 lay = (torch.tensor(cu, dtype=torch.int32).to(dev), torch.cat(pos).to(dev),
                        (C.c_int32 * len(groups))(*groups))
                 self._seq_cache[key] = lay
+                while len(self._seq_cache) > _SEQ_CACHE_ENTRIES:
+                    self._seq_cache.popitem(last=False)
             cu, pos, groups = lay
             T = T_pad
             smax = max(S for _, S in shapes)
-        rg, rl = self._rope_tables(max(smax, 64), dev)
-        wc = self._weights()
-        nbytes = fn("snx_model_workspace_bytes")(C.byref(self._desc), T, nseq, int(save))
-        saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        sparse = torch.empty((nseq, self.geom.vocab_size), dtype=torch.float32, device=dev)
-        tw = torch.empty((T,), dtype=torch.float32, device=dev)
-        check(fn("snx_model_forward")(C.byref(self._desc), self._param_ptrs(), _p(wc), _p(ids), _p(mask), _p(cu),
-                                      _p(pos), _p(rg), _p(rl), _p(saved), _p(sparse), _p(tw),
-                                      groups if (len(shapes) > 1 or lengths is not None) else None, T, nseq, smax,
-                                      SNX_FWD_SAVE_FOR_BACKWARD if save else 0, _stream()), "snx_model_forward")
+        with torch.cuda.device(dev):            # native launches go to THIS device's current stream
+            rg, rl = self._rope_tables(max(smax, 64), dev)
+            wc = self._weights()
+            nbytes = fn("snx_model_workspace_bytes")(C.byref(self._desc), T, nseq, int(save))
+            saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            sparse = torch.empty((nseq, self.geom.vocab_size), dtype=torch.float32, device=dev)
+            tw = torch.empty((T,), dtype=torch.float32, device=dev)
+            check(fn("snx_model_forward")(C.byref(self._desc), self._param_ptrs(), _p(wc), _p(ids), _p(mask), _p(cu),
+                                          _p(pos), _p(rg), _p(rl), _p(saved), _p(sparse), _p(tw),
+                                          groups if (len(shapes) > 1 or lengths is not None) else None, T, nseq, smax,
+                                          SNX_FWD_SAVE_FOR_BACKWARD if save else 0, _stream()), "snx_model_forward")
         if scatter is not None:                      # token_weights back to the padded layout (0 at padding)
             tw_full = torch.zeros((T_pad,), dtype=torch.float32, device=dev)
             tw_full[scatter] = tw
@@ -277,12 +340,24 @@ class EncoderRuntime:
                 grads.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             ret = grads
-        nbytes = fn("snx_model_bwd_workspace_bytes")(C.byref(self._desc), T, B, S)
-        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        check(fn("snx_model_backward")(C.byref(self._desc), self._param_ptrs(), self._grad_ptrs(grads),
-                                       _p(self._weights()), _p(ids), _p(mask), _p(cu), _p(pos), _p(rg), _p(rl),
-                                       _p(saved), _p(g), _p(scratch), groups, T, B, S, _stream()),
-              "snx_model_backward")
+        sync = self.grad_sync if (self.direct_grads and self.grad_sync is not None and self.grad_sync.armed) else None
+        with torch.cuda.device(dev):
+            nbytes = fn("snx_model_bwd_workspace_bytes")(C.byref(self._desc), T, B, S)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            args = (C.byref(self._desc), self._param_ptrs(), self._grad_ptrs(grads), _p(self._weights()), _p(ids),
+                    _p(mask), _p(cu), _p(pos), _p(rg), _p(rl), _p(saved), _p(g), _p(scratch), groups, T, B, S)
+            if sync is None:
+                check(fn("snx_model_backward")(*args, _stream()), "snx_model_backward")
+            else:
+                # gradient exchange overlapped with the backward: after each unit range its finished slice of the
+                # flat gradient is all-reduced on the exchange stream while the next range computes
+                L = self.geom.num_hidden_layers
+                for ub, ue in sync.unit_ranges(L + 2):
+                    check(fn("snx_model_backward_units")(*args, ub, ue, C.c_void_p(sync.stream.cuda_stream), _stream()),
+                          "snx_model_backward_units")
+                    for lo, hi in self.unit_param_range(ub, ue):
+                        sync.reduce_slice(self.flat_grad, lo, hi)
+                sync.finished_backward()
         return ret
 
     def __call__(self, input_ids, attention_mask):
@@ -314,7 +389,8 @@ class _SpladeEncodeFn(torch.autograd.Function):
         ctx.n_in = 2 * n_pairs + 1
         sparse, tw, saved, aux = rt.forward_many_impl(pairs, save=True, lengths=lengths)
         ctx.rt, ctx.saved_arena, ctx.aux = rt, saved, aux
-        rt.last_ctx = (saved, aux)          # debugging / parity tests: routing of the latest forward
+        if rt.keep_last_ctx:
+            rt.last_ctx = (saved, aux)      # parity tests: routing of the latest forward
         ctx.mark_non_differentiable(tw)
         return sparse, tw
 

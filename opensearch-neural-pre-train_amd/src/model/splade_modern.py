@@ -157,15 +157,23 @@ class ModernBertMaskedLMWeights(nn.Module):
                 "bos_token_id": 0, "eos_token_id": 1, "cls_token_id": 0, "sep_token_id": 1,
                 "tie_word_embeddings": True, "dtype": "float32"}
 
-    def save_pretrained(self, save_directory: str):
-        """HuggingFace-style export (config.json + model.safetensors with HF key names), the
-        counterpart of ``model.model.save_pretrained`` in ref:scripts/export_v33_hf.py:28-32."""
-        from safetensors.torch import save_file
+    def save_pretrained(self, save_directory: str, safe_serialization: bool = True, **kwargs):
+        """HuggingFace-style export with HF key names, the counterpart of
+        ``model.model.save_pretrained(str(output_dir), safe_serialization=True)`` in
+        ref:scripts/export_v33_hf.py:28-32: config.json + model.safetensors (``safe_serialization=True``) or
+        pytorch_model.bin (False).  The directory loads with stock
+        ``transformers.ModernBertForMaskedLM.from_pretrained`` (the tied ``decoder.weight`` is left out, as
+        transformers does for tied weights).  Other ``PreTrainedModel.save_pretrained`` keywords are accepted
+        and ignored."""
         os.makedirs(save_directory, exist_ok=True)
         with open(os.path.join(save_directory, "config.json"), "w") as f:
             json.dump(self.hf_config_dict(), f, indent=2)
         sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items() if k != "decoder.weight"}
-        save_file(sd, os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+        else:
+            torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
 
 
 def _geometry_from_config(cfg: dict) -> EncoderGeometry:

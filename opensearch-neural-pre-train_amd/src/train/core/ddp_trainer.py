@@ -78,20 +78,38 @@ class NativeDataParallel(nn.Module):
     and call signature as torch DDP).  Parameters are broadcast from rank 0 at construction;
     gradient synchronisation is explicit (``sync_gradients``) and happens once per optimizer step."""
 
-    def __init__(self, module: nn.Module, bucket_mb: int = 0):
+    def __init__(self, module: nn.Module, bucket_mb: int = 0, n_buckets: Optional[int] = None):
         super().__init__()
         self.module = module
         self.bucket_mb = bucket_mb
-        if sdist.world() > 1:
+        rt = module.runtime
+        if sdist.active():
             for p in module.parameters():
                 dist.broadcast(p.data, src=0)
-        module.runtime.enable_direct_grads(True)
+            rt.mark_weights_dirty()          # broadcast writes p.data without bumping p._version
+        rt.enable_direct_grads(True)
+        if n_buckets is None:
+            n_buckets = int(os.environ.get("SNX_GRAD_BUCKETS", "4"))
+        dev = next(module.parameters()).device
+        rt.grad_sync = sdist.BucketedGradSync(dev, n_buckets) if (dev.type == "cuda" and n_buckets > 0) else None
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
+    def arm_gradient_sync(self, on: bool = True) -> None:
+        """Call before the LAST micro-step of an accumulation window: its backward then exchanges each
+        finished gradient bucket over RCCL while the earlier layers' backward still runs."""
+        gs = self.module.runtime.grad_sync
+        if gs is not None:
+            gs.arm(on)
+
     def sync_gradients(self) -> None:
-        sdist.allreduce_flat_grads(self.module.runtime.flat_grad, self.bucket_mb)
+        """Gradients averaged over ranks before the optimizer: wait for the overlapped exchange of the last
+        backward, or (nothing was armed) all-reduce the whole flat buffer now."""
+        rt = self.module.runtime
+        if rt.grad_sync is not None and rt.grad_sync.wait(rt.flat_grad):
+            return
+        sdist.allreduce_flat_grads(rt.flat_grad, self.bucket_mb)
 
     def zero_grad(self, set_to_none: bool = False) -> None:   # keep the flat views alive
         self.module.runtime.zero_grads()
@@ -213,9 +231,13 @@ def _packed_lengths(batch: dict):
 
 
 def micro_step(model, loss_fn: SPLADELossV33, batch: dict, global_step: int, device: torch.device,
-               grad_accum: int, cross_gpu_negatives: bool = False):
-    """One micro-batch: three encoder passes, loss, backward (ref:train_v33_ddp.py:321-364)."""
+               grad_accum: int, cross_gpu_negatives: bool = False, last_of_window: bool = False):
+    """One micro-batch: three encoder passes, loss, backward (ref:train_v33_ddp.py:321-364).
+    ``last_of_window``: this backward completes an accumulation window -> NativeDataParallel overlaps the
+    gradient exchange with it."""
     nb = device.type == "cuda"
+    if isinstance(model, NativeDataParallel):
+        model.arm_gradient_sync(last_of_window)
     lengths = _packed_lengths(batch) if _fuse_passes(model) else None
     q_ids = batch["query_input_ids"].to(device, non_blocking=nb)
     q_mask = batch["query_attention_mask"].to(device, non_blocking=nb)
@@ -240,7 +262,7 @@ def micro_step(model, loss_fn: SPLADELossV33, batch: dict, global_step: int, dev
         if num_negatives > 1:
             negative_repr = negative_repr.view(anchor_repr.shape[0], num_negatives, -1)
         extra = {}
-        if cross_gpu_negatives and sdist.world() > 1:
+        if cross_gpu_negatives and sdist.active():
             positive_repr = sdist.all_gather_with_grad(positive_repr)
             extra["label_offset"] = sdist.rank() * anchor_repr.shape[0]
         loss, loss_dict = loss_fn(anchor_repr=anchor_repr, positive_repr=positive_repr,
@@ -291,7 +313,8 @@ def train_epoch(model, dataloader: DataLoader, loss_fn: SPLADELossV33, optimizer
     for batch_idx, batch in enumerate(progress):
         if debug and batch_idx >= 100:
             break
-        loss, loss_dict = micro_step(model, loss_fn, batch, global_step, device, accum, xneg)
+        loss, loss_dict = micro_step(model, loss_fn, batch, global_step, device, accum, xneg,
+                                     last_of_window=(batch_idx + 1) % accum == 0)
         if (batch_idx + 1) % accum == 0:
             optimizer_step(model, optimizer, scheduler, config)
             global_step += 1

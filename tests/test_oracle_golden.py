@@ -180,13 +180,18 @@ def full_params():
     return cfg, O.perturb_params(O.init_params(cfg, seed=42), seed=7, bias_mean=-0.2)
 
 
-def test_g3_full_size_matches_reference(full_params):
-    """149M-parameter config, B=4, q64/d256 ragged: sparse vectors, top-k, loss terms, gradient
-    norms of all 137 tensors and gradient probes vs the reference (fp32 CPU path)."""
+@pytest.mark.parametrize("name", ["g3_full_fwd_bwd", "g8_full_unsaturated", "g7_cfg5_d512_k4"])
+def test_full_size_matches_reference(full_params, name):
+    """149M-parameter config vs the reference (fp32 CPU path): sparse vectors, top-k, loss terms, gradient
+    norms of all 137 tensors and gradient probes.  g3: B=4, q64/d256 ragged (BASELINE configs 1/2);
+    g8: the same batch at tau=500 (InfoNCE not saturated); g7: BASELINE config 5 -- B=2, q64/d512, k=4
+    negatives viewed [B,k,V] (ref:train_v33_ddp.py:346-350), MarginMSE 0.5 with teacher scores
+    (ref:configs/train_v34_multi_neg.yaml:20-28)."""
     import hashlib
     cfg, params = full_params
-    z = _npz("g3_full_fwd_bwd.npz")
-    meta = json.load(open(os.path.join(G, "g3_full_fwd_bwd.json")))
+    z = _npz(name + ".npz")
+    meta = json.load(open(os.path.join(G, name + ".json")))
+    k_neg = int(meta.get("num_negatives", 1))
     for k, h in meta["weight_sha256"].items():
         assert hashlib.sha256(params[k].contiguous().numpy().tobytes()).hexdigest() == h, k
     b = {k[4:]: _t(z[k]) for k in z.files if k.startswith("in::")}
@@ -208,7 +213,9 @@ def test_g3_full_size_matches_reference(full_params):
         assert torch.equal(ri[:, 1:-1][ok], ti[:, 1:-1][ok])
         assert ok.float().mean() > 0.8
     lc = O.LossConfig(**meta["loss_kwargs"])
-    loss, d = O.loss_v33(lc, reps["q"], reps["p"], reps["n"], meta["global_step"])
+    n3 = reps["n"].view(reps["q"].shape[0], k_neg, -1) if k_neg > 1 else reps["n"]
+    loss, d = O.loss_v33(lc, reps["q"], reps["p"], n3, meta["global_step"], b.get("teacher_pos_scores"),
+                         b.get("teacher_neg_scores"))
     assert loss.item() == pytest.approx(meta["loss"], rel=2e-5)
     for k, v in meta["loss_dict"].items():
         assert d[k] == pytest.approx(v, rel=5e-5, abs=1e-6), k
@@ -224,7 +231,10 @@ def test_g3_full_size_matches_reference(full_params):
         g = leaves[k[8:]].grad
         got = (g[:8, :64] if g.dim() == 2 else g[:512]).numpy()
         ref = z[k]
-        assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-12), k
+        # g8: the unsaturated softmax makes every gradient a difference of near-equal terms (|g| ~1e-4), so
+        # fp32 summation-order noise between the reference's and the oracle's reductions is relatively larger
+        ptol = 1e-2 if name == "g8_full_unsaturated" else 2e-3
+        assert np.abs(got - ref).max() <= ptol * max(np.abs(ref).max(), 1e-12), k
     e = leaves["model.model.embeddings.tok_embeddings.weight"].grad
     np.testing.assert_allclose(e.double().norm(dim=1).float().numpy(), z["gprobe::emb_rownorm"], rtol=5e-3, atol=1e-7)
 

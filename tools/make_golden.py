@@ -16,7 +16,9 @@ reference source is copied.
     python tools/make_golden.py g1 g4      # a subset
 
 Fixtures: g1 tiny fwd/bwd (+g6 edge rows), g2 tiny train_epoch (1-proc and
-2-proc gloo DDP), g3 full-size fwd/bwd summaries, g4 loss-only vectors, g5 collator layout.
+2-proc gloo DDP), g3 full-size fwd/bwd summaries, g4 loss-only vectors, g5 collator layout,
+g6 inference post-processing, g7 BASELINE config 5 (d512, k=4, MarginMSE) at full size, g8 the g3 batch
+with an unsaturated InfoNCE.
 """
 from __future__ import annotations
 
@@ -279,20 +281,18 @@ def g2():
 
 
 # ---------------------------------------------------------------------------------------
-def g3():
-    """full 149M config, B=4, q64/d256 ragged: output summaries + gradient probes (weights are
-    regenerated from the seed by the test; only checksums are stored)."""
+def _full_fixture(name, B, Sq, Sd, k, lkw, step, teacher, batch_seed, extra_probe_rows=False):
+    """Full 149M config through the reference: output summaries + gradient probes (weights are regenerated
+    from the seed by the test; only checksums are stored)."""
     cfg = O.EncoderConfig()
     params = O.perturb_params(O.init_params(cfg, seed=42), seed=7, bias_mean=-0.2)
-    gen = torch.Generator().manual_seed(4242)
-    b = O.synth_batch(4, 64, 256, cfg, gen, k=1, ragged=True)
-    lkw = dict(lambda_q=0.01, lambda_d=0.003, temperature=1.0, flops_warmup_steps=20000,
-               lambda_initial_ratio=0.1)
+    gen = torch.Generator().manual_seed(batch_seed)
+    b = O.synth_batch(B, Sq, Sd, cfg, gen, k=k, ragged=True, teacher=teacher)
     model = build_reference_model(cfg, params)
     loss_fn = ref_loss_module(**lkw)
-    loss, d, reps, tws = run_triplet(model, loss_fn, b, global_step=1000)
+    loss, d, reps, tws = run_triplet(model, loss_fn, b, global_step=step)
     loss.backward()
-    arrs = {"in::" + k: np_(v) for k, v in b.items() if torch.is_tensor(v)}
+    arrs = {"in::" + k_: np_(v) for k_, v in b.items() if torch.is_tensor(v)}
     for tag, r, tw in zip("qpn", reps, tws):
         v, i = torch.topk(r.detach(), 256, dim=-1)
         arrs[f"out::{tag}_topv"], arrs[f"out::{tag}_topi"] = np_(v), np_(i)
@@ -301,6 +301,8 @@ def g3():
         arrs[f"out::{tag}_tw"] = np_(tw)
         arrs[f"out::{tag}_full"] = np_(r.detach()).astype(np.float16)   # coarse full vector (fp16)
         arrs[f"out::d{tag}_sum"] = np_(r.grad.double().sum(-1))
+        if extra_probe_rows:
+            arrs[f"out::d{tag}_row0"] = np_(r.grad[0]).astype(np.float32)
     names, gnorm = [], []
     for n, p in model.named_parameters():
         names.append(n)
@@ -315,14 +317,42 @@ def g3():
     e = pg["model.model.embeddings.tok_embeddings.weight"].grad
     arrs["gprobe::emb_rows"] = np_(e[:16, :64])
     arrs["gprobe::emb_rownorm"] = np_(e.double().norm(dim=1)).astype(np.float32)
-    np.savez_compressed(os.path.join(OUT, "g3_full_fwd_bwd.npz"), **arrs)
-    json.dump({"loss_kwargs": lkw, "global_step": 1000, "loss": float(loss.item()), "loss_dict": d,
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    json.dump({"loss_kwargs": lkw, "global_step": step, "loss": float(loss.item()), "loss_dict": d,
+               "num_negatives": k, "shape": {"B": B, "Sq": Sq, "Sd": Sd},
                "grad_names": names, "grad_norms": gnorm,
-               "weight_sha256": {k: sha(v) for k, v in list(params.items())[:8]},
+               "weight_sha256": {k_: sha(v) for k_, v in list(params.items())[:8]},
                "init": "oracle.init_params(seed=42) + perturb_params(seed=7, bias_mean=-0.2)",
+               "batch": f"oracle.synth_batch(seed={batch_seed}, ragged, teacher={teacher})",
                "transformers": __import__("transformers").__version__, "torch": torch.__version__},
-              open(os.path.join(OUT, "g3_full_fwd_bwd.json"), "w"), indent=1)
-    print("g3 loss", loss.item(), d)
+              open(os.path.join(OUT, name + ".json"), "w"), indent=1)
+    print(name, "loss", loss.item(), d)
+
+
+def g3():
+    """full 149M config, B=4, q64/d256 ragged (BASELINE config 1/2 shape)."""
+    _full_fixture("g3_full_fwd_bwd", 4, 64, 256, 1,
+                  dict(lambda_q=0.01, lambda_d=0.003, temperature=1.0, flops_warmup_steps=20000,
+                       lambda_initial_ratio=0.1), 1000, False, 4242)
+
+
+def g7():
+    """BASELINE config 5 through the reference: full 149M model, B=2, q64 / d512, k=4 `negatives`
+    (flattened [B*k, S] then viewed [B, k, V], ref:train_v33_ddp.py:346-350), MarginMSE 0.5 with teacher
+    scores and the other loss values of ref:configs/train_v34_multi_neg.yaml:20-28."""
+    _full_fixture("g7_cfg5_d512_k4", 2, 64, 512, 4,
+                  dict(lambda_q=0.01, lambda_d=0.003, temperature=1.0, flops_warmup_steps=5000,
+                       lambda_kd=0.0, kd_temperature=1.0, lambda_margin_mse=0.5, lambda_initial_ratio=0.5),
+                  1000, True, 5151, extra_probe_rows=True)
+
+
+def g8():
+    """The g3 batch (same seed -> same ids) at a temperature where InfoNCE is NOT saturated: random-init
+    sparse vectors have dot products ~2e4 with a spread of a few hundred, so tau = 500 puts the logits'
+    spread at O(1) and the softmax coefficients carry information (g3's tau = 1 is a one-hot)."""
+    _full_fixture("g8_full_unsaturated", 4, 64, 256, 1,
+                  dict(lambda_q=0.01, lambda_d=0.003, temperature=500.0, flops_warmup_steps=20000,
+                       lambda_initial_ratio=0.1), 1000, False, 4242, extra_probe_rows=True)
 
 
 # ---------------------------------------------------------------------------------------

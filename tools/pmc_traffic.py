@@ -9,10 +9,24 @@ Corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx
 half of the bytes of wide coalesced reads, so it is doubled; WRITE_SIZE is exact for 16-B stores and float
 atomics.  Infinity-Cache hits are counted (these are fabric bytes, an upper bound on DRAM bytes).
 Kernels are keyed by (short name, grid size) so that the GEMM shapes stay apart."""
+import glob
+import hashlib
 import json
+import os
 import re
 import sqlite3
 import sys
+
+
+def kernel_source_hash() -> str:
+    """Same definition as bench.py: sha256 over csrc/*.hip and *.h."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "opensearch-neural-pre-train_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def short(name: str) -> str:
@@ -42,7 +56,9 @@ def main():
             "fabric_bytes_per_launch": kf * 1024 * 2 + kw * 1024,
         }
     with open(out, "w") as fh:
-        json.dump({"note": "fabric (L2 memory-side) bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; "
+        json.dump({"kernel_source_sha256": kernel_source_hash(),
+                   "workload": "python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline (BASELINE config 2)",
+                   "note": "fabric (L2 memory-side) bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; "
                            "Infinity-Cache hits included", "kernels": res}, fh, indent=1)
     for k, v in list(res.items())[:24]:
         print(f"{v['fabric_bytes_per_launch'] / 1e6:10.1f} MB/launch  n={v['launches']:5d}  {k}")
