@@ -177,8 +177,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    # one process per GPU over RCCL; a 1-rank launch under torchrun with SNX_DIST_FORCE=1 also builds the group, so
+    # that the collectives of the data-parallel path can be rehearsed on a single GPU
+    use_pg = world > 1 or ("RANK" in os.environ and os.environ.get("SNX_DIST_FORCE", "0") == "1")
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group(backend="nccl", device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -220,7 +224,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -233,7 +237,7 @@ def main():
         loss = one_step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -300,7 +304,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -291,6 +291,14 @@ __global__ __launch_bounds__(256) void splade_bwd_dw_kernel(const float* __restr
 // first BUCKETED by target row (counting sort per sequence, integer LDS atomics on S counters
 // only), then one wave per token row gathers its W rows and accumulates in registers -- no float
 // atomics, every dHd row written exactly once (rows without entries get zeros).
+// Slot order inside a row's bucket = vocabulary order, so that the fp32 accumulation order of the gather
+// kernel below -- and with it dHd -- is the same in every run (two-run bit-compare).  Each of the
+// 16 waves owns a contiguous vocabulary range and keeps its own per-row counters; a wave's slots for a row
+// start after those of the waves before it, and inside one 64-entry step lanes that hit the same row are
+// ranked by lane id (wave-uniform loop over the distinct rows of the step: ballot + popcount, no atomics
+// whose arrival order could vary).  DET = false (rows > 1024: the per-wave tables no longer fit) falls back
+// to first-come slots from an LDS atomic counter.
+template <bool DET>
 __global__ __launch_bounds__(1024) void splade_bucket_kernel(const float* __restrict__ g,
                                                              const uint32_t* __restrict__ keys,
                                                              const int32_t* __restrict__ cu_seqlens,
@@ -299,22 +307,43 @@ __global__ __launch_bounds__(1024) void splade_bucket_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) int32_t smi[];
   int32_t* cnt = smi;                    // [max_rows]
   int32_t* off = smi + max_rows;         // [max_rows + 1]
-  int32_t* fill = off + max_rows + 1;    // [max_rows]
+  int32_t* fill = off + max_rows + 1;    // [max_rows]            (DET: unused)
+  int32_t* wtab = fill + max_rows;       // [16][max_rows]        (DET only)
   const int seq = blockIdx.x;
   const int slen = cu_seqlens[seq + 1] - cu_seqlens[seq];
   const int rows = slen < max_rows ? slen : max_rows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < max_rows; i += blockDim.x) { cnt[i] = 0; fill[i] = 0; }
+  if (DET)
+    for (int i = threadIdx.x; i < 16 * max_rows; i += blockDim.x) wtab[i] = 0;
   __syncthreads();
   const float* gs = g + (long)seq * V;
   const uint32_t* ks = keys + (long)seq * V;
-  for (int v = threadIdx.x; v < V; v += blockDim.x) {
-    const uint32_t key = ks[v];
-    const int row = (int)(0xFFFFu - (key & 0xFFFFu));
-    if (splade_coef(gs[v], key) != 0.f && row < rows) atomicAdd(&cnt[row], 1);
+  const int per_wave = ((V + 16 * 64 - 1) / (16 * 64)) * 64;          // vocabulary range of one wave
+  const int vb = wave * per_wave, ve = min(V, vb + per_wave);
+  if (DET) {
+    int32_t* mine = wtab + wave * max_rows;
+    for (int v = vb + lane; v < ve; v += 64) {
+      const uint32_t key = ks[v];
+      const int row = (int)(0xFFFFu - (key & 0xFFFFu));
+      if (splade_coef(gs[v], key) != 0.f && row < rows) atomicAdd(&mine[row], 1);
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {            // wave-exclusive prefix per row + row total
+      int run = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) { const int c = wtab[w * max_rows + r]; wtab[w * max_rows + r] = run; run += c; }
+      cnt[r] = run;
+    }
+  } else {
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      const uint32_t key = ks[v];
+      const int row = (int)(0xFFFFu - (key & 0xFFFFu));
+      if (splade_coef(gs[v], key) != 0.f && row < rows) atomicAdd(&cnt[row], 1);
+    }
   }
   __syncthreads();
   if (threadIdx.x < 64) {                // exclusive scan of cnt[0..rows) by one wave
-    const int lane = threadIdx.x;
     const int per = (rows + 63) / 64;
     int local = 0;
     for (int i = 0; i < per; ++i) {
@@ -337,14 +366,38 @@ __global__ __launch_bounds__(1024) void splade_bucket_kernel(const float* __rest
   __syncthreads();
   int32_t* lv = list_v + (long)seq * V;
   float* lc = list_c + (long)seq * V;
-  for (int v = threadIdx.x; v < V; v += blockDim.x) {
-    const uint32_t key = ks[v];
-    const int row = (int)(0xFFFFu - (key & 0xFFFFu));
-    const float c = splade_coef(gs[v], key);
-    if (c != 0.f && row < rows) {
-      const int slot = off[row] + atomicAdd(&fill[row], 1);
-      lv[slot] = v;
-      lc[slot] = c;
+  if (DET) {
+    int32_t* mine = wtab + wave * max_rows;                           // running slot offset of this wave per row
+    for (int v0 = vb; v0 < ve; v0 += 64) {                            // wave-uniform trip count
+      const int v = v0 + lane;
+      uint32_t key = 0;
+      float c = 0.f;
+      if (v < ve) { key = ks[v]; c = splade_coef(gs[v], key); }
+      const int row = (int)(0xFFFFu - (key & 0xFFFFu));
+      const bool act = c != 0.f && row < rows;
+      unsigned long long todo = __ballot(act);
+      int slot = 0;
+      while (todo) {                                                  // one pass per distinct row of this step
+        const int leader = __ffsll((long long)todo) - 1;
+        const int r = __builtin_amdgcn_readlane(row, leader);
+        const unsigned long long same = __ballot(act && row == r);
+        const int base = off[r] + mine[r];
+        if (act && row == r) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+        if (lane == leader) mine[r] += __popcll(same);
+        todo &= ~same;
+      }
+      if (act) { lv[slot] = v; lc[slot] = c; }
+    }
+  } else {
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      const uint32_t key = ks[v];
+      const int row = (int)(0xFFFFu - (key & 0xFFFFu));
+      const float c = splade_coef(gs[v], key);
+      if (c != 0.f && row < rows) {
+        const int slot = off[row] + atomicAdd(&fill[row], 1);
+        lv[slot] = v;
+        lc[slot] = c;
+      }
     }
   }
   for (int r = threadIdx.x; r <= rows; r += blockDim.x) row_off[(long)seq * (max_rows + 1) + r] = off[r];
@@ -427,11 +480,19 @@ extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* 
   int32_t* list_v = (int32_t*)sc;
   float* list_c = (float*)(sc + (size_t)nseq * V * 4);
   int32_t* row_off = (int32_t*)(sc + (size_t)nseq * V * 8);
-  const size_t lds = (size_t)(3 * max_seqlen + 1) * 4;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)splade_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(splade_bucket_kernel, dim3(nseq), dim3(1024), lds, st, g, keys, cu_seqlens, list_v, list_c,
-                     row_off, V, max_seqlen);
+  const bool det = max_seqlen <= 1024;         // per-wave slot tables fit in LDS: vocabulary-ordered buckets
+  const size_t lds = (size_t)(3 * max_seqlen + 1 + (det ? 16 * max_seqlen : 0)) * 4;
+  if (det) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)splade_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(splade_bucket_kernel<true>, dim3(nseq), dim3(1024), lds, st, g, keys, cu_seqlens, list_v, list_c,
+                       row_off, V, max_seqlen);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)splade_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(splade_bucket_kernel<false>, dim3(nseq), dim3(1024), lds, st, g, keys, cu_seqlens, list_v, list_c,
+                       row_off, V, max_seqlen);
+  }
   SNX_CHECK_LAUNCH();
   const dim3 grid(cdiv(max_seqlen, 4), nseq);
   switch (H / 256) {

@@ -425,16 +425,20 @@ def adamw_step(st: TrainState, grads: Dict[str, torch.Tensor], lr: float, wd: fl
 def train_micro_steps(cfg: EncoderConfig, lc: LossConfig, st: TrainState, batches: List[dict],
                       grad_accum: int, base_lr: float, wd: float, clip: float, warmup: int,
                       total_steps: int, global_step: int = 0, mode: str = "fp32",
-                      world_grads_hook=None):
+                      world_grads_hook=None, route_rows=None, grads_out: Optional[list] = None):
     """The micro-batch loop of ``train_epoch`` (ref:train_v33_ddp.py:316-374) on plain tensors.
-    Returns (per-micro-step losses, per-micro-step loss dicts, global_step)."""
+    Returns (per-micro-step losses, per-micro-step loss dicts, global_step).
+    ``route_rows`` (test-only): per batch a (query, positive, negative) triple of [B, V] max-pool routings
+    to pin (see ``splade_forward``); ``grads_out``: receives the accumulated gradient dict of every
+    optimizer step (before clipping)."""
     losses, dicts = [], []
     acc: Dict[str, torch.Tensor] = {}
     for bi, b in enumerate(batches):
         leaves = {n: p.detach().clone().requires_grad_(True) for n, p in st.params.items()}
-        q, _ = splade_forward(leaves, cfg, b["query_input_ids"], b["query_attention_mask"], mode)
-        p_, _ = splade_forward(leaves, cfg, b["positive_input_ids"], b["positive_attention_mask"], mode)
-        n_, _ = splade_forward(leaves, cfg, b["negative_input_ids"], b["negative_attention_mask"], mode)
+        rq, rp, rn = route_rows[bi] if route_rows is not None else (None, None, None)
+        q, _ = splade_forward(leaves, cfg, b["query_input_ids"], b["query_attention_mask"], mode, rq)
+        p_, _ = splade_forward(leaves, cfg, b["positive_input_ids"], b["positive_attention_mask"], mode, rp)
+        n_, _ = splade_forward(leaves, cfg, b["negative_input_ids"], b["negative_attention_mask"], mode, rn)
         k = int(b.get("num_negatives", 1))
         if k > 1:
             n_ = n_.view(q.shape[0], k, -1)
@@ -449,6 +453,8 @@ def train_micro_steps(cfg: EncoderConfig, lc: LossConfig, st: TrainState, batche
         if (bi + 1) % grad_accum == 0:
             if world_grads_hook is not None:
                 acc = world_grads_hook(acc)
+            if grads_out is not None:
+                grads_out.append({n: g.clone() for n, g in acc.items()})
             lr = base_lr * cosine_lr_factor(global_step, warmup, total_steps)
             adamw_step(st, acc, lr, wd, clip)
             acc = {}

@@ -1,5 +1,6 @@
 """bench.py's one-line JSON contract (the driver parses it): a short real run on the GPU."""
 import json
+import math
 import os
 import subprocess
 import sys
@@ -30,3 +31,23 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"]) and 0.05 < roof["frac"] < 1.0
     assert roof["traffic"] is None or roof["traffic"] > 1e6
     assert 100.0 < d["value"] < 1e5
+    assert math.isfinite(d["config"]["final_loss"])
+    assert "no per-micro-step loss.item()" in d["config"]["workload"]
+    assert roof["traffic_provenance"]["status"].split(":")[0] in ("current", "stale", "absent")
+    assert (roof["traffic"] is None) == (roof["traffic_provenance"]["status"] != "current")
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_one_rank_over_rccl():
+    """`--gpus N` launch path with N = 1: torch.distributed.run, nccl (= RCCL) process group, rank-0 broadcast,
+    bucketed gradient all-reduce overlapped with the last backward of each window (SNX_DIST_FORCE=1)."""
+    env = dict(os.environ, SNX_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "8", "--warmup", "4", "--no-cpu-baseline", "--no-profile"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and math.isfinite(d["config"]["final_loss"]) and 100.0 < d["value"] < 1e5

@@ -1,0 +1,108 @@
+"""Multi-GPU readiness proven on ONE GPU (SURVEY 8(e), rows a15 / e): the collectives of the data-parallel
+path go through RCCL with a world-size-1 `nccl` process group.
+
+  * torch `DistributedDataParallel(device_ids=[0], broadcast_buffers=False, find_unused_parameters=False)`
+    around the model -- the literal drop-in of ref:src/train/cli/train_v33_ddp.py:539-544 -- through
+    `train_epoch` (3 forwards / 1 backward per micro-step, accumulate 4) vs the oracle loop;
+  * `NativeDataParallel` with SNX_DIST_FORCE=1, which removes the world()==1 early-outs so that the rank-0
+    broadcast, the bucketed all_reduce(AVG) overlapped with the backward, all_gather_into_tensor and
+    reduce_scatter_tensor really reach RCCL.
+Scaling itself needs more than one GPU and is measured by the driver, not here."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def nccl_world1(dev):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    yield
+    dist.destroy_process_group()
+
+
+def test_torch_ddp_wrapped_train_epoch(dev, nccl_world1):
+    from tests.test_gpu_model import train_epoch_case
+    train_epoch_case(dev, "ddp")
+
+
+def test_native_data_parallel_collectives_reach_rccl(dev, nccl_world1, monkeypatch):
+    """Same micro-steps twice: without collectives (plain world-1 early-outs) and with SNX_DIST_FORCE=1 (rank-0
+    broadcast at wrap, bucketed all-reduce(AVG) during the last backward of the window, all-gather +
+    reduce-scatter of the positives for cross-GPU negatives).  At world size 1 every collective is the
+    identity, so losses must be bit-equal and parameters equal up to fp32 atomic order; the bucket slices must
+    tile the flat gradient exactly once."""
+    from oracle import splade_oracle as O
+    from snx import dist as sdist
+    from src.model.losses import SPLADELossV33
+    from src.train.config.v33 import V33Config
+    from src.train.core import ddp_trainer as T
+    from tests.test_gpu_model import _build_model, _small_cfg
+    cfg = _small_cfg()
+    params = O.perturb_params(O.init_params(cfg, seed=3), seed=4, scale=2.0, bias_mean=-0.1)
+    gen = torch.Generator().manual_seed(77)
+    batches = [O.synth_batch(4, 24, 70, cfg, gen, k=2, ragged=True) for _ in range(4)]
+    conf = V33Config()
+    conf.training.gradient_accumulation_steps = 2
+    conf.training.learning_rate = 1e-3
+
+    def run(force):
+        if force:
+            monkeypatch.setenv("SNX_DIST_FORCE", "1")
+        else:
+            monkeypatch.delenv("SNX_DIST_FORCE", raising=False)
+        assert sdist.active() == force
+        model = T.NativeDataParallel(_build_model(cfg, params, dev), n_buckets=3)
+        loss_fn = SPLADELossV33(temperature=20.0, flops_warmup_steps=4).to(dev)
+        opt = T.build_optimizer(model, conf)
+        sch = T.build_scheduler(opt, 0, 4)
+        losses, slices = [], []
+        gs = 0
+        for i, b in enumerate(batches):
+            last = (i + 1) % 2 == 0
+            loss, _ = T.micro_step(model, loss_fn, b, gs, dev, 2, cross_gpu_negatives=True, last_of_window=last)
+            losses.append(float(loss))
+            if last:
+                slices.append(list(model.module.runtime.grad_sync.slices))
+                T.optimizer_step(model, opt, sch, conf)
+                gs += 1
+        torch.cuda.synchronize()
+        return losses, slices, {n: p.detach().clone() for n, p in model.module.named_parameters()}, model
+
+    l0, s0, p0, _ = run(False)
+    l1, s1, p1, m1 = run(True)
+    assert l0[:2] == l1[:2]                                  # before the first optimizer step: bit-equal
+    for a, b in zip(l0, l1):
+        assert a == pytest.approx(b, rel=1e-4)
+    assert s0 == [[], []]                                    # nothing exchanged without a forced group
+    total = m1.module.runtime.flat_grad.numel()
+    for sl in s1:                                            # forced: 3 buckets tile the flat gradient exactly once
+        cov = sorted(sl)
+        assert cov[0][0] == 0 and cov[-1][1] == total and all(a[1] == b[0] for a, b in zip(cov, cov[1:])), cov
+        assert 3 <= len(sl) <= 5
+    for n in p0:
+        assert torch.allclose(p0[n], p1[n], rtol=1e-4, atol=2e-6), n
+
+
+def test_bucket_plan_covers_every_unit(dev):
+    from snx.dist import BucketedGradSync
+    for nb in (1, 2, 4, 8, 22, 40):
+        r = BucketedGradSync(dev, nb).unit_ranges(24)
+        assert r[0][0] == 0 and r[-1][1] == 24 and all(a[1] == b[0] for a, b in zip(r, r[1:])), (nb, r)
+        assert len(r) == min(nb, 22)

@@ -3,11 +3,14 @@ against the CPU oracle and the committed golden vectors.  Needs a real MI355X: p
 
 Tolerance protocol:
   * loss kernels, fp32 operands ............ vs golden g4 (reference outputs): rel 2e-5
-  * bf16 production path vs the oracle in emulated-bf16 mode (same cast points): sparse values
-    max-abs / mean-abs bounds below, top-k indices exact where the oracle's rank gap > 2x the
-    value error; loss terms rel 5e-3; per-tensor gradient cosine >= 0.999 and rel-L2 <= 3e-2
-  * bf16 production path vs the reference fp32 golden (g3, full size): reported, loose bound
-    (torch's own CPU bf16 autocast vs fp32 gives max 6.9e-3 / mean 1.4e-3 on this model)."""
+  * bf16 production path vs the oracle in emulated-bf16 mode (same cast points): sparse values as an
+    ULP statement (tests/helpers.sparse_ulp_stats: no entry more than one bf16 ulp of the logit away,
+    bounded fraction of one-ulp flips, mean <= 1e-3), top-k indices exact where the oracle's rank gap >
+    2x the value error; loss terms rel 2e-3 under pinned routing; per-tensor gradient cosine >= 0.999
+    and rel-L2 <= 2e-2 under pinned routing (free routing: at the oracle's own bf16-vs-fp32 floor,
+    tests/test_oracle_floor.py)
+  * bf16 production path vs the reference fp32 golden (g3, full size): reported, bound at the
+    bf16-vs-fp32 background (torch's own CPU bf16 autocast vs fp32: max 6.9e-3 / mean 1.4e-3)."""
 import json
 import os
 
@@ -15,7 +18,10 @@ import numpy as np
 import pytest
 import torch
 
+from tests.helpers import sparse_ulp_stats, topk_rank_check
+
 pytestmark = pytest.mark.gpu
+FLIPPED_MAX = 0.12      # see tests/test_gpu_parity_full.py
 G = os.path.join(os.path.dirname(__file__), "golden")
 OUT = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
 
@@ -76,9 +82,10 @@ def _grad_stats(got, ref):
 def test_small_model_forward_backward_vs_oracle(dev, k, margin, Sq, Sd, cos_min, rel_max):
     """Gradient tolerance: the max-pool routes each (b, v) gradient to ONE sequence position; bf16
     logits tie or nearly tie often, so a 1-ulp accumulation-order flip re-routes that entry.  With
-    free routing the oracle's OWN bf16-vs-fp32 gradients agree only to cos ~0.99 / rel ~0.14 at
-    q40/d150 (measured), so these cases are held to cos >= 0.98 / rel <= 0.2 and the
-    numbers are reported; the tight bound is enforced by the pinned-routing test below."""
+    free routing the oracle's OWN bf16-vs-fp32 gradients agree only to cos 0.989-0.994 / rel 0.11-0.15 on
+    exactly these cases (tests/test_oracle_floor.py asserts that floor on the CPU), so they are held to
+    cos >= 0.98 / rel <= 0.2 and the numbers are reported; the tight bound is enforced by the
+    pinned-routing test below."""
     from oracle import splade_oracle as O
     from src.model.losses import SPLADELossV33
     cfg = _small_cfg()
@@ -113,20 +120,16 @@ def test_small_model_forward_backward_vs_oracle(dev, k, margin, Sq, Sd, cos_min,
     loss.backward()
     rep = {}
     for tag, got, ref in (("q", q, oq), ("p", p, op), ("n", n, on), ("qt", qt, oqt), ("pt", pt, opt)):
-        diff = (got.detach().cpu() - ref.detach()).abs()
-        rep[tag] = {"max": float(diff.max()), "mean": float(diff.mean()), "scale": float(ref.abs().max())}
+        rep[tag] = st = sparse_ulp_stats(got, ref)
         assert torch.isfinite(got).all()
-        assert diff.max().item() < 0.03 * max(1.0, rep[tag]["scale"]), (tag, rep[tag])
-        assert diff.mean().item() < 2e-3, (tag, rep[tag])
+        assert st["bad"] == 0, (tag, st)                       # never more than one bf16 ulp of the logit
+        assert st["flipped"] <= FLIPPED_MAX and st["mean_abs"] <= 1e-3, (tag, st)
     # padded positions are exactly zero
     assert (pt.detach().cpu()[b["positive_attention_mask"] == 0] == 0).all()
     # top-k indices exact where the oracle gap allows
-    ov, oi = torch.topk(op.detach(), 32, dim=-1)
-    gv, gi = torch.topk(p.detach().cpu(), 32, dim=-1)
-    gap = (ov[:, :-1] - ov[:, 1:]) > 2 * max(rep["p"]["max"], 1e-6)
-    ok = gap[:, 1:] & gap[:, :-1]
-    assert torch.equal(oi[:, 1:-1][ok], gi[:, 1:-1][ok])
-    rep["topk_checked_frac"] = float(ok.float().mean())
+    tk = topk_rank_check(p, op, 32, max(rep["p"]["max_abs"], 1e-6))
+    assert tk["equal"], tk
+    rep["topk"] = tk
     rep["loss"] = {"got": float(loss), "ref": float(oloss)}
     assert float(loss) == pytest.approx(float(oloss), rel=5e-3)
     for key in ("infonce", "flops_q", "flops_d", "flops_neg", "margin_mse", "nonzero_q", "nonzero_d"):
@@ -159,6 +162,7 @@ def test_small_model_gradients_with_pinned_routing(dev, k, margin, Sq, Sd):
     lc = O.LossConfig(lambda_q=0.01, lambda_d=0.003, temperature=20.0, flops_warmup_steps=50,
                       lambda_initial_ratio=0.1, lambda_margin_mse=margin)
     model = _build_model(cfg, params, dev)
+    model.runtime.keep_last_ctx = True
     loss_fn = SPLADELossV33(lambda_q=lc.lambda_q, lambda_d=lc.lambda_d, temperature=lc.temperature,
                             flops_warmup_steps=lc.flops_warmup_steps, lambda_initial_ratio=lc.lambda_initial_ratio,
                             lambda_margin_mse=margin).to(dev)
@@ -178,7 +182,7 @@ def test_small_model_gradients_with_pinned_routing(dev, k, margin, Sq, Sd):
     on3 = o["negative"].view(6, k, -1) if k > 1 else o["negative"]
     oloss, _ = O.loss_v33(lc, o["query"], o["positive"], on3, 20, b.get("teacher_pos_scores"), b.get("teacher_neg_scores"), "bf16")
     oloss.backward()
-    assert float(loss) == pytest.approx(float(oloss), rel=5e-3)
+    assert float(loss) == pytest.approx(float(oloss), rel=2e-3)
     stats = {name: _grad_stats(prm.grad.cpu(), leaves[name].grad) for name, prm in model.named_parameters()}
     worst = min(stats.items(), key=lambda kv: kv[1][0])
     _report(f"small_pinned_routing_k{k}", {"worst": [worst[0], *worst[1]], "max_rel": max(v[1] for v in stats.values())})
@@ -259,7 +263,7 @@ def test_full_size_vs_reference_golden_g3(dev, full_setup):
             rep[tag] = {"full_max": float(diff.max()), "full_mean": float(diff.mean()), "top256_val_max": float(tdiff.max()),
                         "top50_overlap": float(overlap), "tw_max": float(twd.max()), "scale": float(rv.max())}
             assert torch.isfinite(sr).all()
-            assert diff.max().item() < 0.05 and diff.mean().item() < 4e-3, rep[tag]
+            assert diff.max().item() < 1.5e-2 and diff.mean().item() < 2e-3, rep[tag]
             assert overlap > 0.85, rep[tag]
         lf = SPLADELossV33(**meta["loss_kwargs"]).to(dev)
         loss, d = lf(anchor_repr=outs["q"], positive_repr=outs["p"], negative_repr=outs["n"],
@@ -287,30 +291,6 @@ def test_full_size_vs_reference_golden_g3(dev, full_setup):
     for n_, (cos, rel) in probe.items():   # bf16 path vs fp32 reference, saturated InfoNCE: noise floor ~0.98
         assert cos > 0.95, (n_, cos, rel)
     model.zero_grad(set_to_none=True)
-
-
-def test_full_size_vs_oracle_bf16(dev, full_setup):
-    """Same inputs, HIP vs the oracle with the SAME bf16 cast points (tight)."""
-    from oracle import splade_oracle as O
-    cfg, params, model = full_setup
-    gen = torch.Generator().manual_seed(777)
-    ids, mask = O.synth_ids(2, 256, cfg, gen, ragged=True)
-    with torch.no_grad():
-        ref, ref_tw = O.splade_forward(params, cfg, ids, mask, "bf16")
-        got, got_tw = model(ids.to(dev), mask.to(dev))
-    diff = (got.cpu() - ref).abs()
-    rep = {"max": float(diff.max()), "mean": float(diff.mean()), "p999": float(diff.flatten().kthvalue(int(diff.numel() * 0.999)).values)}
-    ov, oi = torch.topk(ref, 64, dim=-1)
-    gv, gi = torch.topk(got.cpu(), 64, dim=-1)
-    gap = (ov[:, :-1] - ov[:, 1:]) > 2 * max(rep["max"], 1e-6)
-    ok = gap[:, 1:] & gap[:, :-1]
-    rep["topk_exact_where_checked"] = bool(torch.equal(oi[:, 1:-1][ok], gi[:, 1:-1][ok]))
-    rep["topk_checked_frac"] = float(ok.float().mean())
-    rep["top10_equal"] = bool(torch.equal(oi[:, :10], gi[:, :10]))
-    _report("full_vs_oracle_bf16", rep)
-    assert diff.max().item() < 1e-2 and diff.mean().item() < 1e-3, rep
-    assert rep["topk_exact_where_checked"]
-    assert (got_tw.cpu()[mask == 0] == 0).all()
 
 
 def test_inference_matches_training_forward(dev, full_setup):
@@ -418,11 +398,15 @@ def test_unpadded_execution_equals_padded(dev):
         m2.forward_many(pairs, [lengths[0] * 0, lengths[1], lengths[2]])
 
 
-@pytest.mark.parametrize("native", [True, False])
-def test_train_epoch_vs_oracle_loop(dev, native):
-    """rows a14/a15: the trainer's micro-batch loop (accumulate 4, clip, AdamW with the wd-grouping
-    quirk, cosine warm-up LR, lambda schedule on global_step) on the HIP path vs the oracle's
-    restated loop in emulated-bf16 mode: 8 micro-steps = 2 optimizer steps."""
+def train_epoch_case(dev, mode):
+    """rows a14/a15: the trainer's micro-batch loop (accumulate 4, clip, AdamW with the wd-grouping quirk, cosine
+    warm-up LR, lambda schedule on global_step; ref:train_v33_ddp.py:289-448) on the HIP path vs the oracle's
+    restated loop in emulated-bf16 mode: 8 micro-steps = 2 optimizer steps.  The oracle back-propagates through
+    the max-pool routing each HIP forward chose, so the comparison is tight: per-micro-step losses, the
+    ACCUMULATED gradients handed to each optimizer step, and the PARAMETER VALUES after the two steps.
+    mode: "native" (NativeDataParallel + fused AdamW), "plain" (bare module + torch AdamW),
+    "ddp" (torch DistributedDataParallel around the module: the literal drop-in of ref:train_v33_ddp.py:539-544;
+    needs an initialised process group)."""
     from torch.utils.data import DataLoader, Dataset
     from oracle import splade_oracle as O
     from src.model.losses import SPLADELossV33
@@ -441,9 +425,6 @@ def test_train_epoch_vs_oracle_loop(dev, native):
     conf.loss.temperature = 20.0
     lc = O.LossConfig(lambda_q=conf.loss.lambda_q, lambda_d=conf.loss.lambda_d, temperature=20.0,
                       flops_warmup_steps=4, lambda_initial_ratio=conf.loss.lambda_initial_ratio)
-    st = O.TrainState({n: p.clone() for n, p in params.items()})
-    ref_losses, _, gs_ref = O.train_micro_steps(cfg, lc, st, batches, grad_accum=4, base_lr=2e-3, wd=0.01, clip=1.0,
-                                                warmup=1, total_steps=4, global_step=0, mode="bf16")
 
     class DS(Dataset):
         def __len__(self):
@@ -452,31 +433,84 @@ def test_train_epoch_vs_oracle_loop(dev, native):
         def __getitem__(self, i):
             return batches[i]
     dl = DataLoader(DS(), batch_size=None, shuffle=False)
-    model = _build_model(cfg, params, dev)
-    if native:
-        model = T.NativeDataParallel(model)
+    inner = _build_model(cfg, params, dev)
+    rt = inner.runtime
+    captured = []
+    orig = rt.forward_many_impl
+
+    def capturing(pairs, save, lengths=None):           # max-pool routing of every native forward
+        out = orig(pairs, save, lengths)
+        if save:
+            captured.append(rt.routing_rows(out[2], out[3]).cpu())
+        return out
+    rt.forward_many_impl = capturing
+    if mode == "native":
+        model = T.NativeDataParallel(inner)
+    elif mode == "ddp":
+        model = T.DDP(inner, device_ids=[dev.index or 0], broadcast_buffers=False, find_unused_parameters=False)
+    else:
+        model = inner
     loss_fn = SPLADELossV33(lambda_q=conf.loss.lambda_q, lambda_d=conf.loss.lambda_d, temperature=20.0,
                             flops_warmup_steps=4, lambda_initial_ratio=conf.loss.lambda_initial_ratio).to(dev)
     rec = []
     loss_fn.register_forward_hook(lambda m, i, o: rec.append(o[0].detach()))
     opt = T.build_optimizer(model, conf)
     sch = T.build_scheduler(opt, 1, 4)
+    step_grads = []
+    opt.register_step_pre_hook(lambda o, a, k: step_grads.append(
+        {n_: p.grad.detach().clone().cpu() for n_, p in inner.named_parameters()}))
     avg, gs = T.train_epoch(model, dl, loss_fn, opt, sch, conf, epoch=1, global_step=0, device=dev)
-    assert gs == gs_ref == 2
     got = [float(x) for x in rec]
-    assert avg == pytest.approx(sum(got) / 8, rel=1e-5)
+    assert gs == 2 and avg == pytest.approx(sum(got) / 8, rel=1e-5)
+
+    # routing per micro-step as (query, positive, negative) triples
+    rows_all = torch.cat(captured, 0)
+    assert rows_all.shape[0] == 8 * 12
+    routes = [tuple(rows_all[12 * i + 4 * j: 12 * i + 4 * j + 4] for j in range(3)) for i in range(8)]
+    st = O.TrainState({n: p.clone() for n, p in params.items()})
+    ref_grads = []
+    ref_losses, _, gs_ref = O.train_micro_steps(cfg, lc, st, batches, grad_accum=4, base_lr=2e-3, wd=0.01, clip=1.0,
+                                                warmup=1, total_steps=4, global_step=0, mode="bf16",
+                                                route_rows=routes, grads_out=ref_grads)
+    assert gs_ref == 2
     for i, (a, b) in enumerate(zip(got, ref_losses)):
-        assert a == pytest.approx(b, rel=(5e-3 if i < 4 else 3e-2)), (i, got, ref_losses)
-    # the two optimizer steps moved the weights the same way
-    inner = T.unwrap(model)
+        assert a == pytest.approx(b, rel=2e-3), (i, got, ref_losses)
+    rep = {"losses": got, "ref": ref_losses}
+    # accumulated gradients of both optimizer steps
+    assert len(step_grads) == 2 == len(ref_grads)
+    for si in range(2):
+        # torch's clip_grad_norm_ has already scaled .grad when the step hook fires; the fused optimizer clips inside
+        total = sum(float((g.double() ** 2).sum()) for g in ref_grads[si].values()) ** 0.5
+        coef = 1.0 if mode == "native" else min(1.0, 1.0 / (total + 1e-6))
+        stats = {n_: _grad_stats(step_grads[si][n_], ref_grads[si][n_] * coef) for n_ in ref_grads[si]}
+        worst = min(stats.items(), key=lambda kv: kv[1][0])
+        rep[f"step{si}_worst_grad"] = [worst[0], *worst[1]]
+        bad = {n_: v for n_, v in stats.items() if v[0] < 0.999 or v[1] > 2e-2}
+        assert not bad, (si, bad)
+    # parameter values after the two optimizer steps.  lr(step 0) = 0 (warm-up), lr(step 1) = 2e-3, and an Adam
+    # update is lr * m/(sqrt(v)+eps) with |m/sqrt(v)| ~ 1: elements whose gradient is small against its 1-2 %
+    # bf16-level error may take a different update, everything else must agree to a few % of lr.
+    lr = 2e-3
     num = den1 = den2 = 0.0
+    worst_mean, worst_frac = 0.0, 0.0
     for n_, p in inner.named_parameters():
         d_got = (p.detach().cpu() - params[n_]).double().flatten()
         d_ref = (st.params[n_] - params[n_]).double().flatten()
         num += float(d_got @ d_ref); den1 += float(d_got @ d_got); den2 += float(d_ref @ d_ref)
+        err = (d_got - d_ref).abs()
+        worst_mean = max(worst_mean, float(err.mean()) / lr)
+        worst_frac = max(worst_frac, float((err > 0.1 * lr).double().mean()))
+        assert float(err.max()) <= 2.0 * lr * 1.01, n_
     cos = num / ((den1 * den2) ** 0.5)
-    _report(f"train_epoch_native{int(native)}", {"losses": got, "ref": ref_losses, "update_cos": cos})
-    assert cos > 0.9, cos
+    rep.update({"update_cos": cos, "worst_mean_abs_err_over_lr": worst_mean, "worst_frac_err_gt_0.1lr": worst_frac})
+    _report(f"train_epoch_{mode}", rep)
+    assert cos > 0.995, cos
+    assert worst_mean < 0.05 and worst_frac < 0.1, rep
+
+
+@pytest.mark.parametrize("mode", ["native", "plain"])
+def test_train_epoch_vs_oracle_loop(dev, mode):
+    train_epoch_case(dev, mode)
 
 
 def test_inference_encoder_matches_reference_postprocessing(dev):

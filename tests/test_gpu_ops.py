@@ -311,7 +311,8 @@ def test_gemm_tn_layout(dev):
     assert torch.equal(dw, x.float()[perm])
 
 
-@pytest.mark.parametrize("S,window", [(64, -1), (256, 64), (200, 8), (130, -1), (320, 64), (300, -1)])
+# (512, *): BASELINE config 5 documents -- streaming kernels, 8 key tiles on global layers, 129-key band on local ones
+@pytest.mark.parametrize("S,window", [(64, -1), (256, 64), (200, 8), (130, -1), (320, 64), (300, -1), (512, -1), (512, 64)])
 def test_attention_bwd(dev, S, window):
     from oracle import splade_oracle as O
     ops = _ops()

@@ -1,0 +1,269 @@
+"""Full-size (149 M) parity of the HIP path at the SURVEY 8(d) protocol, incl. BASELINE config 5.
+
+  * values: an ULP statement (tests/helpers.sparse_ulp_stats) vs the oracle in emulated-bf16 mode;
+  * loss terms rel <= 2e-3 and per-tensor gradients cos >= 0.999 / rel-L2 <= 2e-2 vs the oracle back-propagating
+    through the SAME max-pool routing the HIP forward chose (the only discontinuity of the path);
+  * the reference's own fp32 outputs (goldens g7 = config 5, g8 = g3 batch with an unsaturated InfoNCE) beside
+    it, at the looser bf16-vs-fp32 bounds;
+  * a top-k fixture whose rank gaps exceed the value error, so that index equality is actually asserted.
+Needs a real MI355X: pytest -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import sparse_ulp_stats, topk_rank_check
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+OUT = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+
+# measured on MI355X (profiles/r02_parity_report.jsonl): 4-7 % of the entries land on the neighbouring bf16
+# value of the logit; a kernel that is one ulp off everywhere would read ~100 %
+FLIPPED_MAX = 0.12
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _report(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_report.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **obj}) + "\n")
+
+
+def _grad_stats(got, ref):
+    g, r = got.double().flatten(), ref.double().flatten()
+    return float((g @ r) / (g.norm() * r.norm() + 1e-30)), float((g - r).norm() / (r.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def full(dev):
+    from oracle import splade_oracle as O
+    from tests.test_gpu_model import _build_model
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cfg = O.EncoderConfig()
+    params = O.perturb_params(O.init_params(cfg, seed=42), seed=7, bias_mean=-0.2)
+    model = _build_model(cfg, params, dev)
+    model.runtime.keep_last_ctx = True
+    return cfg, params, model
+
+
+def _run_hip(model, dev, b, lkw, step, k):
+    from src.model.losses import SPLADELossV33
+    D = lambda t: t.to(dev) if torch.is_tensor(t) else t   # noqa: E731
+    model.zero_grad(set_to_none=True)
+    outs, tws, rows = {}, {}, {}
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        for tag in ("query", "positive", "negative"):
+            outs[tag], tws[tag] = model(D(b[tag + "_input_ids"]), D(b[tag + "_attention_mask"]))
+            rows[tag] = model.runtime.routing_rows(*model.runtime.last_ctx).cpu()
+        B = outs["query"].shape[0]
+        n3 = outs["negative"].view(B, k, -1) if k > 1 else outs["negative"]
+        lf = SPLADELossV33(**lkw).to(dev)
+        loss, d = lf(anchor_repr=outs["query"], positive_repr=outs["positive"], negative_repr=n3, global_step=step,
+                     teacher_pos_scores=D(b.get("teacher_pos_scores")), teacher_neg_scores=D(b.get("teacher_neg_scores")))
+    loss.backward()
+    return outs, tws, rows, loss, d
+
+
+def _run_oracle(cfg, params, b, lkw, step, k, rows):
+    from oracle import splade_oracle as O
+    leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    free, pinned = {}, {}
+    for tag in ("query", "positive", "negative"):
+        with torch.no_grad():
+            free[tag] = O.splade_forward(params, cfg, b[tag + "_input_ids"], b[tag + "_attention_mask"], "bf16")
+        pinned[tag] = O.splade_forward(leaves, cfg, b[tag + "_input_ids"], b[tag + "_attention_mask"], "bf16",
+                                       route_rows=rows[tag])[0]
+    B = pinned["query"].shape[0]
+    n3 = pinned["negative"].view(B, k, -1) if k > 1 else pinned["negative"]
+    lc = O.LossConfig(**lkw)
+    loss, d = O.loss_v33(lc, pinned["query"], pinned["positive"], n3, step, b.get("teacher_pos_scores"),
+                         b.get("teacher_neg_scores"), "bf16")
+    loss.backward()
+    return free, loss, d, {n: l.grad for n, l in leaves.items()}
+
+
+def _check_against_oracle(name, model, outs, tws, loss, d, free, oloss, od, ograds, b):
+    rep = {}
+    for tag in ("query", "positive", "negative"):
+        st = sparse_ulp_stats(outs[tag], free[tag][0])
+        stw = sparse_ulp_stats(tws[tag], free[tag][1])
+        rep[tag] = {"sparse": st, "token_weights": stw}
+        assert torch.isfinite(outs[tag]).all()
+        assert st["bad"] == 0 and stw["bad"] == 0, (tag, st, stw)                 # never more than one bf16 ulp of the logit
+        assert st["flipped"] <= FLIPPED_MAX and st["mean_abs"] <= 1e-3, (tag, st)
+        assert (tws[tag].detach().cpu()[b[tag + "_attention_mask"] == 0] == 0).all()
+    rep["loss"] = {"got": float(loss), "oracle_bf16_pinned": float(oloss)}
+    assert float(loss) == pytest.approx(float(oloss), rel=2e-3)
+    for key in ("infonce", "flops_q", "flops_d", "flops_neg", "margin_mse"):
+        assert float(d[key]) == pytest.approx(od[key], rel=2e-3, abs=2e-3), (key, float(d[key]), od[key])
+    stats = {n_: _grad_stats(p.grad.cpu(), ograds[n_]) for n_, p in model.named_parameters()}
+    worst = min(stats.items(), key=lambda kv: kv[1][0])
+    rep["worst_grad"] = [worst[0], *worst[1]]
+    rep["max_grad_rel"] = max(v[1] for v in stats.values())
+    rep["grad_norm_ratio_minmax"] = [min(float(p.grad.double().norm() / ograds[n_].double().norm()) for n_, p in model.named_parameters()),
+                                     max(float(p.grad.double().norm() / ograds[n_].double().norm()) for n_, p in model.named_parameters())]
+    _report(name, rep)
+    bad = {n_: v for n_, v in stats.items() if v[0] < 0.999 or v[1] > 2e-2}
+    assert not bad, bad
+    return rep
+
+
+def _check_against_reference(name, model, outs, loss, d, z, meta):
+    """bf16 path vs the reference's fp32 golden: reported; bounds at the bf16-vs-fp32 background level
+    (torch's own CPU bf16 autocast vs fp32 gives max 6.9e-3 / mean 1.4e-3 on this model)."""
+    rep = {}
+    for tag, key in (("q", "query"), ("p", "positive"), ("n", "negative")):
+        ref_full = torch.from_numpy(z[f"out::{tag}_full"].astype(np.float32))
+        sr = outs[key].detach().cpu()
+        diff = (sr - ref_full).abs()
+        ti = torch.topk(sr, 50, dim=-1).indices
+        ri = torch.from_numpy(z[f"out::{tag}_topi"])[:, :50]
+        overlap = float(np.mean([len(set(a.tolist()) & set(b_.tolist())) / 50 for a, b_ in zip(ti, ri)]))
+        rep[tag] = {"max": float(diff.max()), "mean": float(diff.mean()), "top50_overlap": overlap}
+        assert diff.max().item() < 1.5e-2 and diff.mean().item() < 2e-3, rep[tag]
+        assert overlap > 0.85, rep[tag]
+    rep["loss"] = {"got": float(loss), "reference_fp32": meta["loss"]}
+    for key in ("flops_q", "flops_d", "flops_neg"):
+        assert float(d[key]) == pytest.approx(meta["loss_dict"][key], rel=1e-2), key
+    norms = dict(zip(meta["grad_names"], meta["grad_norms"]))
+    ratios = {n_: float(p.grad.double().norm()) / max(norms[n_], 1e-30) for n_, p in model.named_parameters()}
+    rep["grad_norm_ratio_minmax"] = [min(ratios.values()), max(ratios.values())]
+    pg = dict(model.named_parameters())
+    probe = {}
+    for key in z.files:
+        if key.startswith("gprobe::model"):
+            g = pg[key[8:]].grad
+            probe[key[8:]] = _grad_stats((g[:8, :64] if g.dim() == 2 else g[:512]).cpu(), torch.from_numpy(z[key]))
+    rep["grad_probe_cos_rel"] = probe
+    _report(name, rep)
+    return rep
+
+
+def _golden(name):
+    z = np.load(os.path.join(G, name + ".npz"))
+    meta = json.load(open(os.path.join(G, name + ".json")))
+    b = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in::")}
+    return z, meta, b
+
+
+def test_config5_d512_k4_margin_mse(dev, full):
+    """BASELINE config 5 at full size: q64 / d512, k = 4 negatives ([B*k, S] -> view [B, k, V],
+    ref:train_v33_ddp.py:346-350), MarginMSE 0.5 with teacher scores (ref:configs/train_v34_multi_neg.yaml:20-28).
+    512-token sequences run the streaming attention kernels (global layers: S = 512 keys; local: 129-key band)
+    and four decoder row chunks."""
+    cfg, params, model = full
+    z, meta, b = _golden("g7_cfg5_d512_k4")
+    k = meta["num_negatives"]
+    outs, tws, rows, loss, d = _run_hip(model, dev, b, meta["loss_kwargs"], meta["global_step"], k)
+    ref_rep = _check_against_reference("cfg5_vs_reference_fp32_g7", model, outs, loss, d, z, meta)
+    # MarginMSE squares margins of a few thousand: the reference's fp32 value is reproduced by the bf16 path
+    assert float(d["margin_mse"]) == pytest.approx(meta["loss_dict"]["margin_mse"], rel=5e-3), float(d["margin_mse"])
+    assert float(loss) == pytest.approx(meta["loss"], rel=5e-3)
+    for n_, (cos, rel) in ref_rep["grad_probe_cos_rel"].items():
+        assert cos > 0.99, (n_, cos, rel)            # MarginMSE-dominated gradient: smooth in the sparse values
+    free, oloss, od, ograds = _run_oracle(cfg, params, b, meta["loss_kwargs"], meta["global_step"], k, rows)
+    _check_against_oracle("cfg5_vs_oracle_bf16", model, outs, tws, loss, d, free, oloss, od, ograds, b)
+    model.zero_grad(set_to_none=True)
+
+
+def test_unsaturated_infonce_full_size(dev, full):
+    """The g3 batch (B=4, q64/d256) at tau = 500: InfoNCE carries information (g3's tau = 1 is a one-hot on
+    dot products ~2e4), so loss and gradients discriminate.  vs oracle-bf16 under pinned routing at the
+    protocol's bounds, and vs the reference's fp32 run (g8) for the gradient-norm question of round 1."""
+    cfg, params, model = full
+    z, meta, b = _golden("g8_full_unsaturated")
+    outs, tws, rows, loss, d = _run_hip(model, dev, b, meta["loss_kwargs"], meta["global_step"], 1)
+    ref_rep = _check_against_reference("unsaturated_vs_reference_fp32_g8", model, outs, loss, d, z, meta)
+    assert float(d["infonce"]) == pytest.approx(meta["loss_dict"]["infonce"], abs=0.1)     # bf16 mm at |score| ~40
+    free, oloss, od, ograds = _run_oracle(cfg, params, b, meta["loss_kwargs"], meta["global_step"], 1, rows)
+    rep = _check_against_oracle("unsaturated_vs_oracle_bf16", model, outs, tws, loss, d, free, oloss, od, ograds, b)
+    # against the matching-precision oracle there is no one-sided gradient-norm bias
+    lo, hi = rep["grad_norm_ratio_minmax"]
+    assert 0.98 < lo and hi < 1.02, (lo, hi)
+    model.zero_grad(set_to_none=True)
+
+
+def test_topk_indices_exact_on_a_fixture_that_bites(dev, full):
+    """'top-k token indices bit-exact' (north star) is vacuous on near-flat random-init outputs (round 1: <1 % of
+    the ranks were comparable).  Here 160 vocabulary ids get a decoder-bias ladder spaced 2 % apart in
+    log1p space, i.e. well above one bf16 ulp of the logit, so that most of the top-64 ranks are separated
+    by more than twice the value error and their INDICES must agree with the oracle."""
+    from oracle import splade_oracle as O
+    cfg, params, model = full
+    gen = torch.Generator().manual_seed(4321)
+    ladder_ids = torch.randperm(cfg.vocab_size - 10, generator=gen)[:160] + 6
+    j = torch.arange(160, dtype=torch.float32)
+    ladder = 3.5 * torch.exp(0.02 * j) - 1.0                      # logits 2.5 .. 84
+    p2 = dict(params)
+    bias = params["model.decoder.bias"].clone()
+    bias[ladder_ids] = ladder
+    p2["model.decoder.bias"] = bias
+    old = model.model.decoder.bias.detach().clone()
+    try:
+        with torch.no_grad():
+            model.model.decoder.bias.copy_(bias.to(dev))
+        ids, mask = O.synth_ids(4, 256, cfg, torch.Generator().manual_seed(778), ragged=True)
+        with torch.no_grad():
+            ref, _ = O.splade_forward(p2, cfg, ids, mask, "bf16")
+            got, _ = model(ids.to(dev), mask.to(dev))
+    finally:
+        with torch.no_grad():
+            model.model.decoder.bias.copy_(old)
+    st = sparse_ulp_stats(got, ref)
+    tk = topk_rank_check(got, ref, 64, st["max_abs"])
+    _report("topk_ladder", {"ulp": st, "topk": tk})
+    assert st["bad"] == 0, st
+    assert tk["checked_frac"] >= 0.5, tk
+    assert tk["equal"], tk
+
+
+def test_full_size_values_ulp_statement(dev, full):
+    """Forward only, 2 x 256 ragged tokens, default (near-flat) outputs: the ULP statement at full size."""
+    from oracle import splade_oracle as O
+    cfg, params, model = full
+    ids, mask = O.synth_ids(2, 256, cfg, torch.Generator().manual_seed(777), ragged=True)
+    with torch.no_grad():
+        ref, ref_tw = O.splade_forward(params, cfg, ids, mask, "bf16")
+        got, got_tw = model(ids.to(dev), mask.to(dev))
+    st, stw = sparse_ulp_stats(got, ref), sparse_ulp_stats(got_tw, ref_tw)
+    tk = topk_rank_check(got, ref, 64, st["max_abs"])
+    _report("full_vs_oracle_bf16_ulp", {"sparse": st, "token_weights": stw, "topk": tk})
+    assert st["bad"] == 0 and stw["bad"] == 0, (st, stw)
+    assert st["flipped"] <= FLIPPED_MAX and st["mean_abs"] <= 1e-3, st
+    assert tk["equal"], tk
+    assert (got_tw.cpu()[mask == 0] == 0).all()
+
+
+def test_two_runs_are_reproducible(dev, full):
+    """SURVEY 5 'deterministic two-run bit-compare': same inputs twice through forward + backward.
+    Forward outputs, token weights and the max-pool routing are BIT-identical (no atomics in the forward);
+    the routed decoder backward is deterministic too (bucket slots are assigned in vocabulary order).
+    Order-dependent by design: the weight-gradient GEMMs, the LayerNorm weight gradients and the embedding
+    scatter add their per-workgroup partial sums with fp32 global atomics -- bounded here at a relative
+    L2 of 1e-5 per tensor; the decoder bias gradient has a fixed summation order and must be bit-equal."""
+    cfg, params, model = full
+    z, meta, b = _golden("g8_full_unsaturated")
+    runs = []
+    for _ in range(2):
+        outs, tws, rows, loss, d = _run_hip(model, dev, b, meta["loss_kwargs"], meta["global_step"], 1)
+        runs.append((outs, tws, rows, float(loss), {n_: p.grad.detach().clone() for n_, p in model.named_parameters()}))
+    (o1, t1, r1, l1, g1), (o2, t2, r2, l2, g2) = runs
+    for tag in ("query", "positive", "negative"):
+        assert torch.equal(o1[tag], o2[tag]) and torch.equal(t1[tag], t2[tag]) and torch.equal(r1[tag], r2[tag]), tag
+    assert l1 == l2
+    spread = {n_: float((g1[n_] - g2[n_]).double().norm() / (g1[n_].double().norm() + 1e-30)) for n_ in g1}
+    exact = [n_ for n_, v in spread.items() if v == 0.0]
+    _report("two_run_determinism", {"max_rel_spread": max(spread.values()), "bitwise_equal_tensors": len(exact),
+                                    "tensors": len(spread)})
+    assert max(spread.values()) < 1e-5, max(spread.items(), key=lambda kv: kv[1])
+    assert "model.decoder.bias" in exact, spread["model.decoder.bias"]
+    model.zero_grad(set_to_none=True)
