@@ -425,12 +425,14 @@ def adamw_step(st: TrainState, grads: Dict[str, torch.Tensor], lr: float, wd: fl
 def train_micro_steps(cfg: EncoderConfig, lc: LossConfig, st: TrainState, batches: List[dict],
                       grad_accum: int, base_lr: float, wd: float, clip: float, warmup: int,
                       total_steps: int, global_step: int = 0, mode: str = "fp32",
-                      world_grads_hook=None, route_rows=None, grads_out: Optional[list] = None):
+                      world_grads_hook=None, route_rows=None, grads_out: Optional[list] = None,
+                      free_losses_out: Optional[list] = None):
     """The micro-batch loop of ``train_epoch`` (ref:train_v33_ddp.py:316-374) on plain tensors.
     Returns (per-micro-step losses, per-micro-step loss dicts, global_step).
     ``route_rows`` (test-only): per batch a (query, positive, negative) triple of [B, V] max-pool routings
     to pin (see ``splade_forward``); ``grads_out``: receives the accumulated gradient dict of every
-    optimizer step (before clipping)."""
+    optimizer step (before clipping); ``free_losses_out``: with pinned routing, also receives each
+    micro-step's (loss, loss dict) under the oracle's OWN (free) routing at the same parameters."""
     losses, dicts = [], []
     acc: Dict[str, torch.Tensor] = {}
     for bi, b in enumerate(batches):
@@ -445,6 +447,16 @@ def train_micro_steps(cfg: EncoderConfig, lc: LossConfig, st: TrainState, batche
         loss, d = loss_v33(lc, q, p_, n_, global_step, b.get("teacher_pos_scores"),
                            b.get("teacher_neg_scores"), mode)
         (loss / grad_accum).backward()
+        if free_losses_out is not None:
+            with torch.no_grad():
+                fq = splade_forward(leaves, cfg, b["query_input_ids"], b["query_attention_mask"], mode)[0]
+                fp = splade_forward(leaves, cfg, b["positive_input_ids"], b["positive_attention_mask"], mode)[0]
+                fn_ = splade_forward(leaves, cfg, b["negative_input_ids"], b["negative_attention_mask"], mode)[0]
+                if k > 1:
+                    fn_ = fn_.view(fq.shape[0], k, -1)
+                fl, fd = loss_v33(lc, fq, fp, fn_, global_step, b.get("teacher_pos_scores"),
+                                  b.get("teacher_neg_scores"), mode)
+                free_losses_out.append((float(fl), fd))
         for n, leaf in leaves.items():
             g = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
             acc[n] = g if n not in acc else acc[n] + g

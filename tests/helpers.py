@@ -31,27 +31,45 @@ class StubTokenizer:
         open(os.path.join(path, "stub_tokenizer.txt"), "w").write("stub\n")
 
 
-def sparse_ulp_stats(got: torch.Tensor, ref: torch.Tensor, logit_abs_tol: float = 2e-3) -> dict:
+def sparse_ulp_stats(got: torch.Tensor, ref: torch.Tensor, logit_abs_tol: float = 1.2e-2) -> dict:
     """The SURVEY 8(d)(ii) value check as an ULP statement.  Both tensors are fp32 ``log1p(relu(x))`` of a
-    bf16 logit x (the reference's cast points), so ``expm1`` recovers x and the two sides can be compared in
-    units of the bf16 grid the logit lives on:
+    bf16 logit x (the reference's cast points), so ``expm1`` recovers x and the two sides can be compared on
+    the bf16 grid the logit lives on.
 
-      * ``flipped``  -- fraction of entries whose logits are different bf16 values (a one-ulp flip happens when
-        fp32 accumulation-order / upstream one-ulp noise straddles a rounding boundary);
-      * ``bad``      -- entries that differ by MORE than one bf16 ulp AND by more than ``logit_abs_tol`` in the
-        logit (the absolute floor matters only where the bf16 ulp is smaller than the upstream noise,
-        i.e. |x| < 0.25, including entries clipped to 0 by the ReLU on one side only);
-      * ``max_abs`` / ``mean_abs`` on the sparse values themselves.
-    A kernel that is off by several ulps anywhere, or by one ulp everywhere, fails on ``bad`` / ``flipped``."""
+    Noise model (measured on MI355X): two correct bf16 implementations differ in ~15-20 % of the
+    bf16 activations by one ulp (fp32 summation order straddling a rounding boundary).  ~150 such flips
+    among the 768 inputs of a decoder row move its fp32 logit by sigma ~= sqrt(150) * ulp(h) * |E| ~= 2e-3
+    ABSOLUTE, independent of the logit's size.  The rounded logit therefore lands on the neighbouring bf16
+    value with probability ~E|noise| / ulp(x): ~10 % for x in [2, 4) (ulp 2^-6), ~20 % for x in [1, 2), and
+    small logits (ulp < sigma) move by several of their (tiny) ulps.  Returned fractions (they add up to 1
+    together with far / n):
+
+      * ``ulp0`` same bf16 logit; ``ulp1`` / ``ulp2`` neighbouring / next-but-one value;
+      * ``floor`` 3+ ulps apart but within ``logit_abs_tol`` = 6 sigma in the logit (small logits only);
+      * ``far`` (count) everything else: must be empty;
+    plus ``max_abs`` / ``mean_abs`` / ``bias`` (signed mean) of the difference of the sparse values themselves.
+    A kernel that is several ulps off on the large logits fails on ``far``, one that is one ulp off everywhere on
+    ``ulp0``, a systematic rounding error on ``bias``."""
     g, r = got.detach().double().cpu(), ref.detach().double().cpu()
     xg, xr = torch.expm1(g).float(), torch.expm1(r).float()
     ig = xg.to(torch.bfloat16).view(torch.int16).to(torch.int32)        # non-negative floats: bit patterns are ordered
     ir = xr.to(torch.bfloat16).view(torch.int16).to(torch.int32)
     d = (ig - ir).abs()
-    far = (d > 1) & ((xg - xr).abs() > logit_abs_tol)
-    diff = (g - r).abs()
-    return {"flipped": float((d != 0).float().mean()), "bad": int(far.sum()), "max_ulps": int(d[~far].max()) if (~far).any() else 0,
-            "max_abs": float(diff.max()), "mean_abs": float(diff.mean()), "n": int(d.numel())}
+    within = (xg - xr).abs() <= logit_abs_tol
+    n = float(d.numel())
+    diff = g - r
+    return {"ulp0": float((d == 0).sum()) / n, "ulp1": float((d == 1).sum()) / n, "ulp2": float((d == 2).sum()) / n,
+            "floor": float(((d > 2) & within).sum()) / n, "far": int(((d > 2) & ~within).sum()),
+            "max_abs": float(diff.abs().max()), "mean_abs": float(diff.abs().mean()), "bias": float(diff.mean()),
+            "n": int(n)}
+
+
+def assert_ulp_statement(st: dict, what=""):
+    """Bounds from the measured distribution (profiles/r02_parity_report.jsonl: ulp0 0.74-0.89, ulp1 0.11-0.25,
+    ulp2 + floor <= 0.012, far 0, max 5.2e-3, mean 3.6-5.3e-4)."""
+    assert st["far"] == 0, (what, st)
+    assert st["ulp0"] >= 0.6 and st["ulp2"] + st["floor"] <= 0.03, (what, st)
+    assert st["mean_abs"] <= 1e-3 and st["max_abs"] <= 8e-3 and abs(st["bias"]) <= 2e-4, (what, st)
 
 
 def topk_rank_check(got: torch.Tensor, ref: torch.Tensor, k: int, err: float) -> dict:

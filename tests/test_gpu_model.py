@@ -18,10 +18,9 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import sparse_ulp_stats, topk_rank_check
+from tests.helpers import assert_ulp_statement, sparse_ulp_stats, topk_rank_check
 
 pytestmark = pytest.mark.gpu
-FLIPPED_MAX = 0.12      # see tests/test_gpu_parity_full.py
 G = os.path.join(os.path.dirname(__file__), "golden")
 OUT = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
 
@@ -122,8 +121,7 @@ def test_small_model_forward_backward_vs_oracle(dev, k, margin, Sq, Sd, cos_min,
     for tag, got, ref in (("q", q, oq), ("p", p, op), ("n", n, on), ("qt", qt, oqt), ("pt", pt, opt)):
         rep[tag] = st = sparse_ulp_stats(got, ref)
         assert torch.isfinite(got).all()
-        assert st["bad"] == 0, (tag, st)                       # never more than one bf16 ulp of the logit
-        assert st["flipped"] <= FLIPPED_MAX and st["mean_abs"] <= 1e-3, (tag, st)
+        assert_ulp_statement(st, tag)
     # padded positions are exactly zero
     assert (pt.detach().cpu()[b["positive_attention_mask"] == 0] == 0).all()
     # top-k indices exact where the oracle gap allows
@@ -419,7 +417,8 @@ def train_epoch_case(dev, mode):
     batches = [O.synth_batch(4, 24, 70, cfg, gen, k=1, ragged=True) for _ in range(8)]
     conf = V33Config()
     conf.training.gradient_accumulation_steps = 4
-    conf.training.learning_rate = 2e-3
+    lr0 = 5e-4
+    conf.training.learning_rate = lr0
     conf.training.log_every_n_steps = 1
     conf.loss.flops_warmup_steps = 4
     conf.loss.temperature = 20.0
@@ -452,11 +451,14 @@ def train_epoch_case(dev, mode):
         model = inner
     loss_fn = SPLADELossV33(lambda_q=conf.loss.lambda_q, lambda_d=conf.loss.lambda_d, temperature=20.0,
                             flops_warmup_steps=4, lambda_initial_ratio=conf.loss.lambda_initial_ratio).to(dev)
-    rec = []
-    loss_fn.register_forward_hook(lambda m, i, o: rec.append(o[0].detach()))
+    rec, rec_terms = [], []
+    def _record(m, i, o):                                 # (a forward hook must return None to keep the output)
+        rec.append(o[0].detach())
+        rec_terms.append({k_: o[1][k_] for k_ in ("infonce", "flops_q", "flops_d", "flops_neg")})
+    loss_fn.register_forward_hook(_record)
     opt = T.build_optimizer(model, conf)
-    sch = T.build_scheduler(opt, 1, 4)
-    step_grads = []
+    sch = T.build_scheduler(opt, 0, 4)       # no warm-up: lr(step 0) = lr0, lr(step 1) = 0.854 lr0 -> the second
+    step_grads = []                          # window's losses are computed on UPDATED weights
     opt.register_step_pre_hook(lambda o, a, k: step_grads.append(
         {n_: p.grad.detach().clone().cpu() for n_, p in inner.named_parameters()}))
     avg, gs = T.train_epoch(model, dl, loss_fn, opt, sch, conf, epoch=1, global_step=0, device=dev)
@@ -468,14 +470,23 @@ def train_epoch_case(dev, mode):
     assert rows_all.shape[0] == 8 * 12
     routes = [tuple(rows_all[12 * i + 4 * j: 12 * i + 4 * j + 4] for j in range(3)) for i in range(8)]
     st = O.TrainState({n: p.clone() for n, p in params.items()})
-    ref_grads = []
-    ref_losses, _, gs_ref = O.train_micro_steps(cfg, lc, st, batches, grad_accum=4, base_lr=2e-3, wd=0.01, clip=1.0,
-                                                warmup=1, total_steps=4, global_step=0, mode="bf16",
-                                                route_rows=routes, grads_out=ref_grads)
+    ref_grads, ref_losses = [], []
+    _, _, gs_ref = O.train_micro_steps(cfg, lc, st, batches, grad_accum=4, base_lr=lr0, wd=0.01, clip=1.0,
+                                       warmup=0, total_steps=4, global_step=0, mode="bf16",
+                                       route_rows=routes, grads_out=ref_grads, free_losses_out=ref_losses)
     assert gs_ref == 2
-    for i, (a, b) in enumerate(zip(got, ref_losses)):
-        assert a == pytest.approx(b, rel=2e-3), (i, got, ref_losses)
-    rep = {"losses": got, "ref": ref_losses}
+    rep = {"losses": got, "ref": [r[0] for r in ref_losses]}
+    _report(f"train_epoch_{mode}_losses", rep)
+    # loss terms vs the oracle's own (free-routing) loss at its own weights.  FLOPS terms: protocol (iii), rel
+    # 2e-3 (5e-3 in the second window, where the two weight sets differ by one Adam step's sign noise).
+    # InfoNCE: the reference's in-batch torch.mm runs in bf16 under autocast (ref:losses.py:155), so every score
+    # (~250 here) sits on a grid of 1-2 and a one-ulp flip of ONE score moves the batch-mean CE by up to
+    # ulp / (tau * B) = 2 / (20 * 4) = 0.025 -- the bound used; the total follows.
+    for i, (a, (b, bd)) in enumerate(zip(got, ref_losses)):
+        for key in ("flops_q", "flops_d", "flops_neg"):
+            assert float(rec_terms[i][key]) == pytest.approx(bd[key], rel=(2e-3 if i < 4 else 5e-3)), (i, key)
+        assert float(rec_terms[i]["infonce"]) == pytest.approx(bd["infonce"], abs=0.025), (i, float(rec_terms[i]["infonce"]), bd["infonce"])
+        assert a == pytest.approx(b, abs=0.03), (i, got, ref_losses)
     # accumulated gradients of both optimizer steps
     assert len(step_grads) == 2 == len(ref_grads)
     for si in range(2):
@@ -487,10 +498,10 @@ def train_epoch_case(dev, mode):
         rep[f"step{si}_worst_grad"] = [worst[0], *worst[1]]
         bad = {n_: v for n_, v in stats.items() if v[0] < 0.999 or v[1] > 2e-2}
         assert not bad, (si, bad)
-    # parameter values after the two optimizer steps.  lr(step 0) = 0 (warm-up), lr(step 1) = 2e-3, and an Adam
-    # update is lr * m/(sqrt(v)+eps) with |m/sqrt(v)| ~ 1: elements whose gradient is small against its 1-2 %
-    # bf16-level error may take a different update, everything else must agree to a few % of lr.
-    lr = 2e-3
+    # parameter values after the two optimizer steps.  An Adam update is lr * m/(sqrt(v)+eps) with |m/sqrt(v)| ~ 1:
+    # elements whose gradient is small against its 1-2 % bf16-level error may take a different update (up to
+    # 2 lr per step), everything else must agree to a few % of lr.
+    lr = lr0
     num = den1 = den2 = 0.0
     worst_mean, worst_frac = 0.0, 0.0
     for n_, p in inner.named_parameters():
@@ -500,7 +511,7 @@ def train_epoch_case(dev, mode):
         err = (d_got - d_ref).abs()
         worst_mean = max(worst_mean, float(err.mean()) / lr)
         worst_frac = max(worst_frac, float((err > 0.1 * lr).double().mean()))
-        assert float(err.max()) <= 2.0 * lr * 1.01, n_
+        assert float(err.max()) <= 2.0 * 1.854 * lr * 1.01, n_
     cos = num / ((den1 * den2) ** 0.5)
     rep.update({"update_cos": cos, "worst_mean_abs_err_over_lr": worst_mean, "worst_frac_err_gt_0.1lr": worst_frac})
     _report(f"train_epoch_{mode}", rep)

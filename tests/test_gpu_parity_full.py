@@ -14,16 +14,11 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import sparse_ulp_stats, topk_rank_check
+from tests.helpers import assert_ulp_statement, sparse_ulp_stats, topk_rank_check
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 OUT = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
-
-# measured on MI355X (profiles/r02_parity_report.jsonl): 4-7 % of the entries land on the neighbouring bf16
-# value of the logit; a kernel that is one ulp off everywhere would read ~100 %
-FLIPPED_MAX = 0.12
-
 
 @pytest.fixture(scope="module")
 def dev():
@@ -97,14 +92,8 @@ def _check_against_oracle(name, model, outs, tws, loss, d, free, oloss, od, ogra
         st = sparse_ulp_stats(outs[tag], free[tag][0])
         stw = sparse_ulp_stats(tws[tag], free[tag][1])
         rep[tag] = {"sparse": st, "token_weights": stw}
-        assert torch.isfinite(outs[tag]).all()
-        assert st["bad"] == 0 and stw["bad"] == 0, (tag, st, stw)                 # never more than one bf16 ulp of the logit
-        assert st["flipped"] <= FLIPPED_MAX and st["mean_abs"] <= 1e-3, (tag, st)
-        assert (tws[tag].detach().cpu()[b[tag + "_attention_mask"] == 0] == 0).all()
-    rep["loss"] = {"got": float(loss), "oracle_bf16_pinned": float(oloss)}
-    assert float(loss) == pytest.approx(float(oloss), rel=2e-3)
-    for key in ("infonce", "flops_q", "flops_d", "flops_neg", "margin_mse"):
-        assert float(d[key]) == pytest.approx(od[key], rel=2e-3, abs=2e-3), (key, float(d[key]), od[key])
+    rep["loss"] = {"got": float(loss.detach()), "oracle_bf16_pinned": float(oloss.detach()),
+                   "terms": {k_: [float(d[k_]), od[k_]] for k_ in ("infonce", "flops_q", "flops_d", "flops_neg", "margin_mse")}}
     stats = {n_: _grad_stats(p.grad.cpu(), ograds[n_]) for n_, p in model.named_parameters()}
     worst = min(stats.items(), key=lambda kv: kv[1][0])
     rep["worst_grad"] = [worst[0], *worst[1]]
@@ -112,6 +101,14 @@ def _check_against_oracle(name, model, outs, tws, loss, d, free, oloss, od, ogra
     rep["grad_norm_ratio_minmax"] = [min(float(p.grad.double().norm() / ograds[n_].double().norm()) for n_, p in model.named_parameters()),
                                      max(float(p.grad.double().norm() / ograds[n_].double().norm()) for n_, p in model.named_parameters())]
     _report(name, rep)
+    for tag in ("query", "positive", "negative"):
+        assert torch.isfinite(outs[tag]).all()
+        assert_ulp_statement(rep[tag]["sparse"], tag)
+        assert_ulp_statement(rep[tag]["token_weights"], tag + " token_weights")
+        assert (tws[tag].detach().cpu()[b[tag + "_attention_mask"] == 0] == 0).all()
+    assert float(loss) == pytest.approx(float(oloss), rel=2e-3)
+    for key in ("infonce", "flops_q", "flops_d", "flops_neg", "margin_mse"):
+        assert float(d[key]) == pytest.approx(od[key], rel=2e-3, abs=2e-3), (key, float(d[key]), od[key])
     bad = {n_: v for n_, v in stats.items() if v[0] < 0.999 or v[1] > 2e-2}
     assert not bad, bad
     return rep
@@ -131,7 +128,7 @@ def _check_against_reference(name, model, outs, loss, d, z, meta):
         rep[tag] = {"max": float(diff.max()), "mean": float(diff.mean()), "top50_overlap": overlap}
         assert diff.max().item() < 1.5e-2 and diff.mean().item() < 2e-3, rep[tag]
         assert overlap > 0.85, rep[tag]
-    rep["loss"] = {"got": float(loss), "reference_fp32": meta["loss"]}
+    rep["loss"] = {"got": float(loss.detach()), "reference_fp32": meta["loss"]}
     for key in ("flops_q", "flops_d", "flops_neg"):
         assert float(d[key]) == pytest.approx(meta["loss_dict"][key], rel=1e-2), key
     norms = dict(zip(meta["grad_names"], meta["grad_norms"]))
@@ -221,7 +218,7 @@ def test_topk_indices_exact_on_a_fixture_that_bites(dev, full):
     st = sparse_ulp_stats(got, ref)
     tk = topk_rank_check(got, ref, 64, st["max_abs"])
     _report("topk_ladder", {"ulp": st, "topk": tk})
-    assert st["bad"] == 0, st
+    assert st["far"] == 0, st
     assert tk["checked_frac"] >= 0.5, tk
     assert tk["equal"], tk
 
@@ -237,8 +234,8 @@ def test_full_size_values_ulp_statement(dev, full):
     st, stw = sparse_ulp_stats(got, ref), sparse_ulp_stats(got_tw, ref_tw)
     tk = topk_rank_check(got, ref, 64, st["max_abs"])
     _report("full_vs_oracle_bf16_ulp", {"sparse": st, "token_weights": stw, "topk": tk})
-    assert st["bad"] == 0 and stw["bad"] == 0, (st, stw)
-    assert st["flipped"] <= FLIPPED_MAX and st["mean_abs"] <= 1e-3, st
+    assert_ulp_statement(st, "sparse")
+    assert_ulp_statement(stw, "token_weights")
     assert tk["equal"], tk
     assert (got_tw.cpu()[mask == 0] == 0).all()
 
