@@ -65,15 +65,16 @@ __device__ __forceinline__ bf16x8 stg32_get(const char* w, int row, int chunk) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool MID>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
-    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N, int K, int tiles_n, int ntiles,
-    EpiArgs e) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N, int K, TileOrder order, int ntiles,
+    int dbg, EpiArgs e) {
   using Core = GemmCore<BM, BN, WAVES_M, WAVES_N>;
   static_assert(Core::WTN == 64 && Core::WTM == 64, "epilogues assume a 64x64 wave tile");
   static_assert(Core::LDS_BYTES >= WAVES_M * WAVES_N * 16384, "16 KiB of staging per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  int tile_m, tile_n;
+  tile_of(order, xcd_remap(blockIdx.x, ntiles), tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   f32x4 acc[Core::MI][Core::NI];
 #pragma unroll
   for (int i = 0; i < Core::MI; ++i)
@@ -88,47 +89,72 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(
   const int rr = lane >> 3, rc = lane & 7;
   const bool wide = (N & 7) == 0;                    // 16-B row-major stores need N % 8 == 0 (else: direct stores)
 
-  // Epilogue operands (residual stream / saved u) are requested BEFORE the K loop, already in the
-  // row-major layout: each is a 64 KB read per tile that would otherwise start only after the last
-  // MFMA.  64 extra VGPRs are free: LDS already limits the CU to two 4-wave workgroups.
+  // Epilogue operands (residual stream / saved u / RoPE table rows), already in the layout the epilogue wants,
+  // are requested INSIDE the K loop behind the DMA of K-tile 1 (gemm_core.h): 16 loads per wave, counted.
+  // 64 extra VGPRs are free: LDS already limits the CU to two 4-wave workgroups.
   constexpr bool PRE = (EPI == EPI_RESID_F32 || EPI == EPI_GEGLU_BWD || EPI == EPI_ROPE);
   f32x4 pre[PRE ? 8 : 1][2];
   const bool rotate = EPI == EPI_ROPE && span0 < N && span0 < e.rope_cols;   // wave-uniform: a head of q or k
-  if (EPI == EPI_ROPE) {
-    // (cos, sin) of this lane's 4 rows x 8 rotation pairs, in the accumulator layout: the dependent
-    // pos -> table loads would otherwise sit at the end of the tile with nothing to hide behind
-    if (rotate) {
+  int prow[Core::MI];                                  // RoPE: positions of this lane's rows
+  auto early = [&]() {
+    if (EPI == EPI_ROPE && rotate) {
 #pragma unroll
       for (int i = 0; i < Core::MI; ++i) {
         const int row = row0 + i * 16 + li;
-        const f32x4* cs = (const f32x4*)(e.rope_tab + (long)e.pos[row < M ? row : M - 1] * 32 + g4);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          pre[i * 2 + j][0] = cs[j * 8];             // pairs j*16 + g4 + {0, 1}
-          pre[i * 2 + j][1] = cs[j * 8 + 1];         // pairs j*16 + g4 + {2, 3}
-        }
+        prow[i] = e.pos[row < M ? row : M - 1];
       }
     }
-  } else if (PRE && wide) {
+  };
+  const bool npre16 = EPI == EPI_ROPE ? rotate : (PRE && wide);
+  auto pre_issue = [&]() {
+    if (EPI == EPI_ROPE) {
+      // (cos, sin) of this lane's 4 rows x 8 rotation pairs, in the accumulator layout
+      if (rotate) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int row = row0 + rr + 8 * k, col = span0 + rc * 8;
-      pre[k][0] = pre[k][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (row < M && col < N) {
+        for (int i = 0; i < Core::MI; ++i) {
+          const f32x4* cs = (const f32x4*)(e.rope_tab + (long)prow[i] * 32 + g4);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            pre[i * 2 + j][0] = cs[j * 8];             // pairs j*16 + g4 + {0, 1}
+            pre[i * 2 + j][1] = cs[j * 8 + 1];         // pairs j*16 + g4 + {2, 3}
+          }
+        }
+      }
+    } else if (PRE && wide) {
+      // every lane loads (addresses clamped into the matrix): the wait in the main loop counts 16 instructions
+      int col = span0 + rc * 8;
+      col = col < N ? col : N - 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int row = row0 + rr + 8 * k;
+        row = row < M ? row : M - 1;
         if (EPI == EPI_RESID_F32) {
           const float* h = e.Hin + (long)row * N + col;
           pre[k][0] = *(const f32x4*)h;
           pre[k][1] = *(const f32x4*)(h + 4);
-        } else {                                     // dy columns [col, col+8) <-> a at u[64q + 8s], g at +32
+        } else {                                       // dy columns [col, col+8) <-> a at u[64q + 8s], g at +32
           const bf16_t* u = e.U + (long)row * (2 * N) + 64 * (col >> 5) + (col & 31);
-          pre[k][0] = *(const f32x4*)u;              // 8 bf16 of a
-          pre[k][1] = *(const f32x4*)(u + 32);       // 8 bf16 of g
+          pre[k][0] = *(const f32x4*)u;                // 8 bf16 of a
+          pre[k][1] = *(const f32x4*)(u + 32);         // 8 bf16 of g
         }
       }
     }
+  };
+  {
+    // dbg bit 0 (bench diagnostics only): every tile loads operand tile (0, 0) -> all operand traffic is L2-resident
+    const int lm = (dbg & 1) ? 0 : m0, ln = (dbg & 1) ? 0 : n0;
+    if (MID) Core::template mainloop_mid<true>(A, K, lm, M, B, K, ln, N, K, smem, acc, pre_issue, npre16, early);
+    else Core::template mainloop<true>(A, K, lm, M, B, K, ln, N, K, smem, acc, pre_issue, npre16, early);
   }
-  if (MID) Core::template mainloop_mid<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
-  else Core::template mainloop<true>(A, K, m0, M, B, K, n0, N, K, smem, acc);
+  if (dbg & 2) {                                     // dbg bit 1: skip the epilogue (keep the accumulators live)
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < Core::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < Core::NI; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 12345.678f) e.C[0] = f2bf(sum);
+    return;
+  }
 
   if (!wide) {                                       // odd widths (tests, tiny heads): direct 8-byte stores
     if (EPI == EPI_STORE_BF16 || EPI == EPI_RESID_F32) {
@@ -242,6 +268,24 @@ static int launch_nt(const void* A, const void* B, int M, int N, int K, const Ep
   constexpr int BM = 128, BN = 128;
   using Core = GemmCore<BM, BN, 2, 2>;
   const int tm = cdiv(M, BM), tn = cdiv(N, BN);
+  // column-group width of the tile order (gemm_core.h): keep an XCD's share of the weight matrix (cg tiles of
+  // BN x K bf16) within ~1.8 MB of its L2 unless re-reading the activation panels ceil(tn / cg) times costs more
+  // than letting the weights spill (estimate: spilled weights are re-fetched ~4x per XCD).
+  static const int cg_env = getenv("SNX_GEMM_CG") ? atoi(getenv("SNX_GEMM_CG")) : -1;
+  static const int dbg = getenv("SNX_GEMM_DBG") ? atoi(getenv("SNX_GEMM_DBG")) : 0;
+  int cg = tn;
+  if (cg_env > 0) cg = cg_env < tn ? cg_env : tn;
+  else if (cg_env < 0) {
+    const double a_bytes = 2.0 * M * K, b_bytes = 2.0 * N * K, cap = 1.8e6;
+    double best = -1;
+    for (int parts = 1; parts <= 4; ++parts) {
+      const int c = cdiv(tn, parts);
+      const double bsub = 2.0 * c * BN * K;
+      const double cost = a_bytes * cdiv(tn, c) + 8.0 * b_bytes * (bsub <= cap ? 1.0 : 4.0);
+      if (best < 0 || cost < best) { best = cost; cg = c; }
+    }
+  }
+  TileOrder order{tm, tn, cdiv(tm, 8), cg};
   // MID: mid-step barrier main loop (gemm_core.h) -- measured faster for the epilogues that also stream a second
   // operand (residual, saved u), slower for the plain long-K shapes.  SNX_GEMM_MID=<bitmask over EPI> overrides.
   static const int mid_mask = getenv("SNX_GEMM_MID") ? atoi(getenv("SNX_GEMM_MID"))
@@ -249,11 +293,11 @@ static int launch_nt(const void* A, const void* B, int M, int N, int K, const Ep
   if ((mid_mask >> EPI) & 1) {
     auto kern = gemm_nt_kernel<BM, BN, 2, 2, EPI, true>;
     hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(Core::NTHREADS), Core::LDS_BYTES, st, (const bf16_t*)A,
-                       (const bf16_t*)B, M, N, K, tn, tm * tn, e);
+                       (const bf16_t*)B, M, N, K, order, tm * tn, dbg, e);
   } else {
     auto kern = gemm_nt_kernel<BM, BN, 2, 2, EPI, false>;
     hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(Core::NTHREADS), Core::LDS_BYTES, st, (const bf16_t*)A,
-                       (const bf16_t*)B, M, N, K, tn, tm * tn, e);
+                       (const bf16_t*)B, M, N, K, order, tm * tn, dbg, e);
   }
   SNX_CHECK_LAUNCH();
   return SNX_OK;
@@ -340,7 +384,7 @@ __device__ __forceinline__ bf16x8 tn_frag(const char* tile, int mb, int cbase, i
   return (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
                                                       float* __restrict__ dW, int M, int N, int K, int tiles_k,
                                                       int ntiles, int rows_per_split, int interleave_I) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

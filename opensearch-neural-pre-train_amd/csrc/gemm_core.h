@@ -102,36 +102,80 @@ struct GemmCore {
   // TRANSPOSED=false: acc[i][j][r] = C[wm*WTM + i*16 + 4g + r][wn*WTN + j*16 + li]   (g = lane>>4, li = lane&15)
   // TRANSPOSED=true : acc[i][j][r] = C[wm*WTM + i*16 + li][wn*WTN + j*16 + 4g + r]   -- each lane owns 4
   //                   CONSECUTIVE columns of one row: 8-byte bf16 / 16-byte fp32 epilogue accesses.
-  template <bool TRANSPOSED = false>
+  // Epilogue operands (residual stream, saved activations, RoPE table rows) are fetched by `pre` -- EXACTLY 16
+  // VGPR-destination vector loads per wave when npre16 is set, none otherwise (wave-uniform).  They are issued in
+  // the LAST BUT ONE K-step, behind the DMA of the last K-tile: the vm counter retires in issue order, so the wait
+  // of the last K-step leaves those 16 in flight (counted vmcnt(16)) and they land under its 32 MFMAs and the
+  // accumulator write-back.  The K loop is split in the source (body / last-but-one / last step) so that the 64
+  // registers holding them are NOT live in the body: requested before the loop they cost the main loop 20-30 %
+  // (register pressure: fragments no longer prefetched; measured with the epilogue compiled out) and every tile
+  // began by waiting for 64 KB of HBM reads.
+  struct NoPre { __device__ __forceinline__ void operator()() const {} };
+
+  // `early` (RoPE: the positions of this lane's rows) runs right BEHIND the prologue DMA: hipcc waits for such
+  // loads where it issues them (it shifts the positions into table offsets at once), which in front of the
+  // prologue cost every tile a full memory round trip before its first DMA went out; behind it the same wait
+  // coincides with the wait for K-tile 0.
+  template <bool TRANSPOSED = false, typename PreFn = NoPre, typename EarlyFn = NoPre>
   static __device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, long lda, int m0, int M,
                                                   const bf16_t* __restrict__ B, long ldb, int n0, int N,
-                                                  int K, char* smem, f32x4 (&acc)[MI][NI]) {
+                                                  int K, char* smem, f32x4 (&acc)[MI][NI], PreFn pre = PreFn(),
+                                                  bool npre16 = false, EarlyFn early = EarlyFn()) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int nk = K / BK;
     stage<BM>(A, lda, m0, M, 0, smem, wave, lane);
     stage<BN>(B, ldb, n0, N, 0, smem + A_BYTES, wave, lane);
-    for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_sched_barrier(0);
+    early();
+    __builtin_amdgcn_sched_barrier(0);
+    // raw barriers: __syncthreads() would add its own vmcnt(0) (an LDS-DMA counts as a pending LDS write) and
+    // drain the loads a counted wait leaves in flight.  The LDS reads of tile kt-1 were consumed by its MFMAs
+    // (the compiler waited lgkmcnt for them), so only the barrier itself is needed.
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                               // tile kt landed; everyone left tile kt-1
+      __builtin_amdgcn_s_barrier();                  // tile kt landed; everyone left tile kt-1
+      __builtin_amdgcn_sched_barrier(0);
       char* cur = smem + (kt & 1) * STAGE_BYTES;
-      if (kt + 1 < nk) {
-        char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-        stage<BM>(A, lda, m0, M, (kt + 1) * BK, nxt, wave, lane);
-        stage<BN>(B, ldb, n0, N, (kt + 1) * BK, nxt + A_BYTES, wave, lane);
-      }
+      char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+      stage<BM>(A, lda, m0, M, (kt + 1) * BK, nxt, wave, lane);
+      stage<BN>(B, ldb, n0, N, (kt + 1) * BK, nxt + A_BYTES, wave, lane);
       compute_step<TRANSPOSED>(cur, wm, wn, lane, acc);
     }
+    if (kt + 1 < nk) {                               // last but one K-step: stage the last tile, then the epilogue loads
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      char* cur = smem + (kt & 1) * STAGE_BYTES;
+      char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+      stage<BM>(A, lda, m0, M, (kt + 1) * BK, nxt, wave, lane);
+      stage<BN>(B, ldb, n0, N, (kt + 1) * BK, nxt + A_BYTES, wave, lane);
+      __builtin_amdgcn_sched_barrier(0);             // keep the loads behind the DMA instructions
+      pre();
+      __builtin_amdgcn_sched_barrier(0);
+      compute_step<TRANSPOSED>(cur, wm, wn, lane, acc);
+      ++kt;
+      if (npre16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {                                         // K = one tile
+      pre();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    compute_step<TRANSPOSED>(smem + (kt & 1) * STAGE_BYTES, wm, wn, lane, acc);
   }
 
   // Variant with a mid-step barrier: once every wave holds the fragments of K-tile kt in registers, the
   // stage they came from is refilled at once with tile kt+2, so a DMA has 1.5 K-steps to land instead of 1
   // (counted vmcnt: the newest tile stays in flight across the step boundary).
-  template <bool TRANSPOSED = false>
+  template <bool TRANSPOSED = false, typename PreFn = NoPre, typename EarlyFn = NoPre>
   static __device__ __forceinline__ void mainloop_mid(const bf16_t* __restrict__ A, long lda, int m0, int M,
                                                       const bf16_t* __restrict__ B, long ldb, int n0, int N,
-                                                      int K, char* smem, f32x4 (&acc)[MI][NI]) {
+                                                      int K, char* smem, f32x4 (&acc)[MI][NI], PreFn pre = PreFn(),
+                                                      bool npre16 = false, EarlyFn early = EarlyFn()) {
     static_assert((BM / 8 / NW) + (BN / 8 / NW) == 8, "vmcnt(8) below = the DMA instructions of one K-tile per wave");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -143,8 +187,14 @@ struct GemmCore {
       stage<BM>(A, lda, m0, M, BK, smem + STAGE_BYTES, wave, lane);
       stage<BN>(B, ldb, n0, N, BK, smem + STAGE_BYTES + A_BYTES, wave, lane);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    early();
+    __builtin_amdgcn_sched_barrier(0);
+    if (nk < 5) { pre(); npre16 = false; }
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      // queue at this wait: [tile kt][tile kt+1] and, for kt = 1 and 2, the 16 epilogue loads issued behind tile 2
+      if ((kt == 1 || kt == 2) && npre16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                  // tile kt landed for every wave
       char* cur = smem + (kt & 1) * STAGE_BYTES;
@@ -182,6 +232,10 @@ struct GemmCore {
         stage<BN>(B, ldb, n0, N, (kt + 2) * BK, cur + A_BYTES, wave, lane);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (kt == 0 && nk >= 5) {
+        pre();
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -209,4 +263,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
   const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return base + (bid >> 3);
+}
+
+// Position `pos` of the XCD-contiguous tile sequence -> (row panel, column tile) of a tm x tn tile grid.
+// The sequence walks SUPER-BLOCKS of `sb_rows` row panels (one per XCD when tm % 8 == 0); inside a super-block
+// it walks column groups of `cg` tiles, and inside a group row panel by row panel.  The workgroups resident
+// on an XCD at one time (64) then need only cg weight tiles (kept <= ~1.8 MB so they stay in the 4 MiB L2
+// beside the streaming activations and outputs) and a handful of activation panels, each shared by the cg
+// tiles that run back to back.  cg = tn is the plain row-panel-major order.  Bijective for any tm, tn.
+struct TileOrder { int tm, tn, sb_rows, cg; };
+__device__ __forceinline__ void tile_of(const TileOrder& o, int pos, int& m, int& n) {
+  const int per_sb = o.sb_rows * o.tn;
+  const int sb = pos / per_sb;
+  const int rows = min(o.sb_rows, o.tm - sb * o.sb_rows);
+  int p = pos - sb * per_sb;
+  const int g = p / (rows * o.cg);
+  const int cols = min(o.cg, o.tn - g * o.cg);
+  p -= g * rows * o.cg;
+  const int r = p / cols;
+  m = sb * o.sb_rows + r;
+  n = g * o.cg + (p - r * cols);
 }

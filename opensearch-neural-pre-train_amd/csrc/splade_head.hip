@@ -20,7 +20,7 @@
 #endif
 
 template <int BM>
-__global__ __launch_bounds__(256) void decoder_splade_kernel(
+__global__ __launch_bounds__(256, 2) void decoder_splade_kernel(
     const bf16_t* __restrict__ Hd, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ cu_seqlens, const int64_t* __restrict__ mask, float* __restrict__ sparse,
     uint32_t* __restrict__ keys, unsigned short* __restrict__ rowpart, int T, int V, int K, int n_tiles,

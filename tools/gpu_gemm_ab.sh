@@ -1,0 +1,7 @@
+#!/bin/bash
+# A/B of NT GEMM knobs at the bench's shapes (one process per setting: the knobs are read once)
+cd "$(dirname "$0")/.."
+for cfg in "SNX_GEMM_MID=0" "SNX_GEMM_MID=0 SNX_GEMM_DBG=2"; do
+  echo "=== $cfg"
+  env $cfg python tools/gpu_epibench.py 2>/dev/null
+done
