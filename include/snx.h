@@ -148,8 +148,6 @@ int snx_cast_transpose_bf16(const float* in, void* out, int32_t R, int32_t C, hi
 
 /* nn.Linear under autocast (hf:271,300,90-91,490): C[M,N] = A[M,K] B[N,K]^T, bf16, fp32 acc. */
 int snx_gemm_nt_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, hipStream_t stream);
-/* same contract, 256x256 ping-pong kernel (one 8-wave workgroup per CU; see csrc/gemm256.hip). */
-int snx_gemm_nt256_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, hipStream_t stream);
 /* ... fused with the fp32 residual add of hf:331-332: Hout = Hin + bf16(A B^T). */
 int snx_gemm_nt_resid(const void* A, const void* B, const float* Hin, float* Hout, int32_t M, int32_t N, int32_t K,
                       hipStream_t stream);
@@ -171,6 +169,18 @@ int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32_t M, int32
 /* same with dY's columns in the interleaved GeGLU order; dW rows land in the natural Wi order. */
 int snx_gemm_tn_accum_interleaved(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K,
                                   hipStream_t stream);
+/* up to 4 weight-gradient problems over the SAME M token rows (the four Linears of one encoder layer, whose
+ * nn.Linear backward torch runs as four GEMMs) in one launch: the concatenated output tiles fill whole rounds of
+ * the resident workgroups (csrc/gemm.hip). */
+typedef struct snx_tn_problem {
+  const void* dY; /* [M, N] bf16 */
+  const void* X;  /* [M, K] bf16 */
+  float* dW;      /* [N, K] fp32, += */
+  int32_t N, K;
+  int32_t interleaved; /* dY columns in the interleaved GeGLU order (N = 2I) */
+  int32_t reserved;
+} snx_tn_problem;
+int snx_gemm_tn_accum_group(const snx_tn_problem* probs /*[host]*/, int32_t nprob, int32_t M, hipStream_t stream);
 
 /* LayerNorm without bias (hf:61,312,314,420,487), fp32 in -> bf16 out. */
 int snx_ln_fwd(const float* h, const float* w, void* x_out, int32_t T, int32_t H, float eps, hipStream_t stream);

@@ -384,9 +384,22 @@ __device__ __forceinline__ bf16x8 tn_frag(const char* tile, int mb, int cbase, i
   return (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
-                                                      float* __restrict__ dW, int M, int N, int K, int tiles_k,
-                                                      int ntiles, int rows_per_split, int interleave_I) {
+// Up to SNX_TN_MAX_GROUP weight-gradient problems that share the token dimension M (the four Linears of one
+// encoder layer) run as ONE launch: their output tiles are concatenated, so that tiles x splits can fill whole
+// rounds of the 512 resident workgroups (a single Wqkv / Wi problem has 108 tiles: 4 splits = 432 workgroups,
+// 84 % of one round; the layer's 306 tiles x 5 splits = 1530 = 99.6 % of three rounds) and only the last
+// round's float atomics are exposed.
+#define SNX_TN_MAX_GROUP 4
+struct TnGroup {
+  const bf16_t* dY[SNX_TN_MAX_GROUP];
+  const bf16_t* X[SNX_TN_MAX_GROUP];
+  float* dW[SNX_TN_MAX_GROUP];
+  int N[SNX_TN_MAX_GROUP], K[SNX_TN_MAX_GROUP], inter[SNX_TN_MAX_GROUP];
+  int tile_end[SNX_TN_MAX_GROUP];       // running tile count after problem p
+  int nprob;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnGroup grp, int M, int ntiles, int rows_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE_BYTES = 64 * 256, STAGE_BYTES = 2 * TILE_BYTES;
   const int lane = threadIdx.x & 63;
@@ -396,7 +409,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   // XCD's L2 work on the SAME token range (neighbouring tiles), so each slice of dY / X is pulled
   // from HBM by one XCD only (measured before: 4x the algorithmic bytes, ~5 TB/s of fabric traffic).
   const int work = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_id = work % ntiles, split = work / ntiles;
+  int tile_id = work % ntiles;
+  const int split = work / ntiles;
+  int p = 0;
+#pragma unroll
+  for (int q = 0; q < SNX_TN_MAX_GROUP - 1; ++q)
+    if (q + 1 < grp.nprob && tile_id >= grp.tile_end[q]) p = q + 1;
+  if (p > 0) tile_id -= grp.tile_end[p - 1];
+  const bf16_t* __restrict__ dY = grp.dY[p];
+  const bf16_t* __restrict__ X = grp.X[p];
+  float* __restrict__ dW = grp.dW[p];
+  const int N = grp.N[p], K = grp.K[p], interleave_I = grp.inter[p];
+  const int tiles_k = K / 128;
   const int n0 = (tile_id / tiles_k) * 128, k0 = (tile_id % tiles_k) * 128;
   const int m_begin = split * rows_per_split;
   const int m_end = min(M, m_begin + rows_per_split);
@@ -461,25 +485,62 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
     }
 }
 
+// splits of the token range: whole rounds of the 512 resident workgroup slots (2 x 64 KiB LDS per CU on 256
+// CUs) are what counts; among the split counts that keep >= 256 tokens per workgroup pick the best-filled one,
+// preferring fewer splits (less float-atomic traffic) when the fill is within 2 %.
+static int tn_pick_splits(int tiles, int M) {
+  static const int forced = getenv("SNX_TN_SPLITS") ? atoi(getenv("SNX_TN_SPLITS")) : 0;
+  const int max_splits = cdiv(M, 256) < 1 ? 1 : cdiv(M, 256);
+  if (forced > 0) return forced < max_splits ? forced : max_splits;
+  int best = 1;
+  double best_fill = 0;
+  for (int s = 1; s <= max_splits && s <= 32 && (long)tiles * s <= 8L * 512; ++s) {
+    const long w = (long)tiles * s;
+    const double fill = (double)w / ((double)cdiv(w, 512) * 512);
+    if (fill > best_fill + 0.02) { best_fill = fill; best = s; }
+  }
+  return best;
+}
+
+static int launch_tn_group(const TnGroup& g, int M, hipStream_t st) {
+  const int tiles = g.tile_end[g.nprob - 1];
+  int splits = tn_pick_splits(tiles, M);
+  int rows = cdiv(M, splits);
+  rows = ((rows + 63) / 64) * 64;
+  splits = cdiv(M, rows);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 2 * 2 * 64 * 256, st, g, M, tiles, rows);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
 static int launch_tn(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K, int interleave_I,
                      hipStream_t st) {
   if (!dY || !X || !dW) return SNX_E_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128)) return SNX_E_SHAPE;
   if (interleave_I < 0 || (interleave_I > 0 && 2 * interleave_I != N)) return SNX_E_SHAPE;
-  const int tiles = (N / 128) * (K / 128);
-  // token-range splits: fill (at most) the 512 resident workgroup slots (2 x 64 KiB LDS per CU on
-  // 256 CUs); more splits than that only add float-atomic traffic
-  int splits = 512 / tiles;
-  const int max_splits = cdiv(M, 256);
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  int rows = cdiv(M, splits);
-  rows = ((rows + 63) / 64) * 64;
-  splits = cdiv(M, rows);
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 2 * 2 * 64 * 256, st, (const bf16_t*)dY,
-                     (const bf16_t*)X, dW, M, N, K, K / 128, tiles, rows, interleave_I);
-  SNX_CHECK_LAUNCH();
-  return SNX_OK;
+  TnGroup g{};
+  g.dY[0] = (const bf16_t*)dY; g.X[0] = (const bf16_t*)X; g.dW[0] = dW;
+  g.N[0] = N; g.K[0] = K; g.inter[0] = interleave_I;
+  g.tile_end[0] = (N / 128) * (K / 128);
+  g.nprob = 1;
+  return launch_tn_group(g, M, st);
+}
+
+extern "C" int snx_gemm_tn_accum_group(const snx_tn_problem* probs, int32_t nprob, int32_t M, hipStream_t st) {
+  if (!probs || nprob < 1 || nprob > SNX_TN_MAX_GROUP || M <= 0) return SNX_E_ARG;
+  TnGroup g{};
+  int run = 0;
+  for (int p = 0; p < nprob; ++p) {
+    const snx_tn_problem& q = probs[p];
+    if (!q.dY || !q.X || !q.dW) return SNX_E_ARG;
+    if (q.N <= 0 || q.K <= 0 || (q.N % 128) || (q.K % 128)) return SNX_E_SHAPE;
+    g.dY[p] = (const bf16_t*)q.dY; g.X[p] = (const bf16_t*)q.X; g.dW[p] = q.dW;
+    g.N[p] = q.N; g.K[p] = q.K; g.inter[p] = q.interleaved ? q.N / 2 : 0;
+    run += (q.N / 128) * (q.K / 128);
+    g.tile_end[p] = run;
+  }
+  g.nprob = nprob;
+  return launch_tn_group(g, M, st);
 }
 
 extern "C" int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K,

@@ -107,11 +107,14 @@ bool plan_saved(const snx_model_desc* d, long T, long nseq, bool save, SavedPlan
 
 struct BwdPlan {
   size_t dh;        // fp32 [T,H]   gradient of the residual stream
-  size_t a, b;      // bf16 [T,H]
-  size_t c;         // bf16 [T,I]
-  size_t w;         // bf16 [T,max(3H,2I)]   du (GeGLU backward output)
-  size_t w2;        // bf16 [T,3H]           dqkv: its own buffer, so that the dW GEMM that still reads du on the
-                    //                       side stream never holds back the attention backward
+  // gradients of the four Linear outputs of a layer, double buffered by layer parity: the layer's weight-gradient
+  // GEMMs run as ONE grouped launch on the side stream after its dX chain, while the next layer already writes
+  // the other set
+  size_t p[2];      // bf16 [T,H]   d(mlp.Wo out)  = bf16(dh) entering the layer
+  size_t du[2];     // bf16 [T,2I]  d(Wi out)      (GeGLU backward output, interleaved)
+  size_t q[2];      // bf16 [T,H]   d(attn.Wo out) = bf16(dh) after the MLP block
+  size_t dqkv[2];   // bf16 [T,3H]  d(Wqkv out)
+  size_t b;         // bf16 [T,H]   scratch (d head.dense out; d attention out)
   size_t delta;     // fp32 [heads,T]
   size_t splade;    // bucket lists of the routed SPLADE backward
   size_t total;
@@ -122,10 +125,10 @@ void plan_bwd(const snx_model_desc* d, long T, long nseq, long max_seqlen, BwdPl
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
   p.dh = take(T * H * 4);
-  p.a = take(T * H * 2); p.b = take(T * H * 2);
-  p.c = take(T * I * 2);
-  p.w = take(T * (3 * H > 2 * I ? 3 * H : 2 * I) * 2);
-  p.w2 = take(T * 3 * H * 2);
+  for (int k = 0; k < 2; ++k) {
+    p.p[k] = take(T * H * 2); p.du[k] = take(T * 2 * I * 2); p.q[k] = take(T * H * 2); p.dqkv[k] = take(T * 3 * H * 2);
+  }
+  p.b = take(T * H * 2);
   p.delta = take((size_t)d->heads * T * 4);
   p.splade = take(snx_splade_bwd_scratch_bytes((int)nseq, (int)max_seqlen, d->vocab));
   p.total = off;
@@ -187,12 +190,20 @@ struct Side {
   std::vector<hipEvent_t> ev;
   size_t next = 0;
   int enabled = -1;
-  hipEvent_t read_a = nullptr, read_du = nullptr, read_dqkv = nullptr;
+  hipEvent_t done[2] = {nullptr, nullptr};   // grouped weight-gradient launch that last read buffer set k
   bool on() {
     if (enabled < 0) {
       const char* e = getenv("SNX_BWD_OVERLAP");
       enabled = (e && e[0] == '0') ? 0 : 1;
-      if (enabled && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) enabled = 0;
+      if (enabled) {
+        // LOWEST priority: the weight-gradient workgroups fill the slots the dX chain leaves free (last partial
+        // round of a GEMM, LayerNorm / attention phases) instead of competing with it.  SNX_SIDE_PRIO=0: default.
+        int least = 0, greatest = 0;
+        const char* pr = getenv("SNX_SIDE_PRIO");
+        const bool low = !(pr && pr[0] == '0');
+        if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, low ? least : 0) != hipSuccess) enabled = 0;
+      }
     }
     return enabled == 1;
   }
@@ -375,15 +386,16 @@ extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* con
   auto G = [&](int idx) { return (float*)grads[idx]; };
   auto hbuf = [&](int i) { return (const float*)(sv + s.h[i]); };
   float* dh = (float*)(sc + b.dh);
-  char *A = sc + b.a, *Bb = sc + b.b, *Wd = sc + b.w, *Wq = sc + b.w2;
+  char* Bb = sc + b.b;
   const long n4 = (long)T * H / 4;
 
-  // dW GEMMs go to the side stream unless the per-class profiler is timing kernels one by one
+  // The weight-gradient GEMMs go to the side stream unless the per-class profiler is timing kernels one by one:
+  // one GROUPED launch per layer (its four Linears), issued after the layer's dX chain.
   const bool overlap = !g_prof.on && g_side.on();
   hipStream_t ss = overlap ? g_side.s : st;
   if (unit_begin == 0) {                              // a new backward: recycle the event pool
     g_side.next = 0;
-    g_side.read_a = g_side.read_du = g_side.read_dqkv = nullptr;
+    g_side.done[0] = g_side.done[1] = nullptr;
   }
   auto fork = [&]() -> int {                          // side stream: wait for everything enqueued on st so far
     if (!overlap) return SNX_OK;
@@ -400,11 +412,10 @@ extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* con
     if (!overlap || !e) return SNX_OK;
     return hipStreamWaitEvent(st, e, 0) == hipSuccess ? SNX_OK : SNX_E_ARG;
   };
-  // last side-stream reader of A / Wd / Wq (kept across the calls of one backward)
-  hipEvent_t &read_a = g_side.read_a, &read_du = g_side.read_du, &read_dqkv = g_side.read_dqkv;
 
   const double TH = (double)T * H;
   if (unit_begin == 0) {
+    char* A = sc + b.p[(L - 1) & 1];                  // d(mlp.Wo out) of the last layer ends up here
     // SPLADE tail + decoder (sparse routed), head
     { PROF(PC_SPLADE_BWD, 2.0 * 2.0 * nseq * V * H);
       RC(snx_splade_bwd(g_sparse, (const uint32_t*)(sv + s.keys), sv + s.hd, wc + c.emb, cu_seqlens, A, G(p.tok_emb()),
@@ -412,7 +423,7 @@ extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* con
     { PROF(PC_LN_BWD, TH * 6); RC(snx_gelu_ln_bwd(A, sv + s.dd, F(p.head_norm()), Bb, G(p.head_norm()), T, H, d->ln_eps, st)); }
     { PROF(PC_GEMM_TN, 2.0 * TH * H); RC(snx_gemm_tn_accum(Bb, sv + s.xf, G(p.head_dense()), T, H, H, st)); }
     { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(Bb, wc + c.dense_t, A, T, H, H, st)); }
-    // every LayerNorm backward also emits bf16(dh) into A: the gradient of the next bf16 branch output
+    // every LayerNorm backward also emits bf16(dh): the gradient of the next bf16 branch output
     { PROF(PC_LN_BWD, TH * 12); RC(snx_ln_bwd(A, hbuf(2 * L), F(p.final_norm()), dh, A, G(p.final_norm()), T, H, d->ln_eps, 1, st)); }
   }
 
@@ -421,45 +432,47 @@ extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* con
   for (int l = l_hi; l >= l_lo && l >= 0; --l) {
     const bool global = (l % d->global_every) == 0;
     const double pairs = attn_pairs(groups, nseq, max_seqlen, global ? -1 : d->window);
+    const int k = l & 1;
+    char *P = sc + b.p[k], *Du = sc + b.du[k], *Q = sc + b.q[k], *Dq = sc + b.dqkv[k], *Pn = sc + b.p[k ^ 1];
+    // this layer overwrites the buffer set the grouped launch of layer l + 2 read (and Pn, read by layer l + 1's)
+    RC(join(g_side.done[k]));
     // ---- MLP:  h[2l+2] = h[2l+1] + Wo( gelu(a) * g ),  [a|g] = Wi( LN(h[2l+1]) )
-    RC(fork());
-    { ProfScope ps(PC_GEMM_TN, 2.0 * TH * I, ss); RC(snx_gemm_tn_accum(A, sv + s.y[l], G(p.wo_mlp(l)), T, H, I, ss)); }
-    RC(mark(read_a));
-    RC(join(read_du));                             // previous layer's dWi has finished reading du
     { PROF(PC_GEMM_NT, 2.0 * TH * I);             // dy = dh Wo, GeGLU backward fused -> du [T,2I] (interleaved)
-      RC(snx_gemm_nt_geglu_bwd(A, wc + c.wom_t[l], sv + s.u[l], Wd, T, I, H, st)); }
-    RC(fork());
-    { ProfScope ps(PC_GEMM_TN, 2.0 * TH * 2 * I, ss); RC(snx_gemm_tn_accum_interleaved(Wd, sv + s.x_mlp[l], G(p.wi(l)), T, 2 * I, H, ss)); }
-    RC(mark(read_du));
-    RC(join(read_a));                              // dWo(mlp) has finished reading A
-    { PROF(PC_GEMM_NT, 2.0 * TH * 2 * I); RC(snx_gemm_nt_bf16(Wd, wc + c.wi_t[l], A, T, H, 2 * I, st)); }   // dx [T,H]
-    { PROF(PC_LN_BWD, TH * 16); RC(snx_ln_bwd(A, hbuf(2 * l + 1), F(p.mlp_norm(l)), dh, A, G(p.mlp_norm(l)), T, H, d->ln_eps, 0, st)); }
+      RC(snx_gemm_nt_geglu_bwd(P, wc + c.wom_t[l], sv + s.u[l], Du, T, I, H, st)); }
+    { PROF(PC_GEMM_NT, 2.0 * TH * 2 * I); RC(snx_gemm_nt_bf16(Du, wc + c.wi_t[l], Q, T, H, 2 * I, st)); }   // dx [T,H]
+    { PROF(PC_LN_BWD, TH * 16); RC(snx_ln_bwd(Q, hbuf(2 * l + 1), F(p.mlp_norm(l)), dh, Q, G(p.mlp_norm(l)), T, H, d->ln_eps, 0, st)); }
     // ---- attention:  h[2l+1] = h[2l] + Wo( attn( rope( Wqkv( LN(h[2l]) ) ) ) )
-    RC(fork());
-    { ProfScope ps(PC_GEMM_TN, 2.0 * TH * H, ss); RC(snx_gemm_tn_accum(A, sv + s.attn[l], G(p.wo(l)), T, H, H, ss)); }
-    RC(mark(read_a));
-    { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(A, wc + c.wo_t[l], Bb, T, H, H, st)); }    // d(attn out)
-    RC(join(read_dqkv));                           // previous layer's dWqkv has finished reading dqkv
+    { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(Q, wc + c.wo_t[l], Bb, T, H, H, st)); }    // d(attn out)
     { PROF(PC_ATTN_BWD, 10.0 * H * pairs);
       RC(snx_attn_bwd_ex(sv + s.qkv[l], sv + s.attn[l], Bb, (const float*)(sv + s.lse[l]), cu_seqlens, mask,
-                         (float*)(sc + b.delta), Wq, global ? rope_global : rope_local, pos, groups, T, nseq,
+                         (float*)(sc + b.delta), Dq, global ? rope_global : rope_local, pos, groups, T, nseq,
                          max_seqlen, d->heads, d->head_dim, global ? -1 : d->window, st)); }      // inverse RoPE fused
+    RC(join(g_side.done[k ^ 1]));                  // layer l + 1's grouped launch has finished reading Pn
+    { PROF(PC_GEMM_NT, 2.0 * TH * 3 * H); RC(snx_gemm_nt_bf16(Dq, wc + c.wqkv_t[l], Pn, T, H, 3 * H, st)); }   // dx [T,H]
+    // the four weight gradients of the layer: dWo(mlp) = P^T y, dWi = du^T x_mlp, dWo(attn) = Q^T attn, dWqkv = dqkv^T x_attn
     RC(fork());
-    { ProfScope ps(PC_GEMM_TN, 2.0 * TH * 3 * H, ss); RC(snx_gemm_tn_accum(Wq, sv + s.x_attn[l], G(p.wqkv(l)), T, 3 * H, H, ss)); }
-    RC(mark(read_dqkv));
-    RC(join(read_a));                              // dWo(attn) has finished reading A
-    { PROF(PC_GEMM_NT, 2.0 * TH * 3 * H); RC(snx_gemm_nt_bf16(Wq, wc + c.wqkv_t[l], A, T, H, 3 * H, st)); }   // dx [T,H]
+    {
+      ProfScope ps(PC_GEMM_TN, 2.0 * TH * (I + 2 * I + H + 3 * H), ss);
+      snx_tn_problem pr[4] = {
+          {Dq, sv + s.x_attn[l], G(p.wqkv(l)), 3 * H, H, 0, 0},
+          {Du, sv + s.x_mlp[l], G(p.wi(l)), 2 * I, H, 1, 0},
+          {P, sv + s.y[l], G(p.wo_mlp(l)), H, I, 0, 0},
+          {Q, sv + s.attn[l], G(p.wo(l)), H, H, 0, 0}};
+      RC(snx_gemm_tn_accum_group(pr, 4, T, ss));
+    }
+    RC(mark(g_side.done[k]));
     if (l > 0) {
       PROF(PC_LN_BWD, TH * 16);
-      RC(snx_ln_bwd(A, hbuf(2 * l), F(p.attn_norm(l)), dh, A, G(p.attn_norm(l)), T, H, d->ln_eps, 0, st));
+      RC(snx_ln_bwd(Pn, hbuf(2 * l), F(p.attn_norm(l)), dh, Pn, G(p.attn_norm(l)), T, H, d->ln_eps, 0, st));
     } else {
       PROF(PC_CAST, TH * 10);
-      hipLaunchKernelGGL(add_bf16_into_f32_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dh, (const bf16_t*)A, n4);
+      hipLaunchKernelGGL(add_bf16_into_f32_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dh, (const bf16_t*)Pn, n4);
       SNX_CHECK_LAUNCH();
     }
   }
   if (unit_end == L + 2) {
-    RC(join(read_dqkv));                           // the side stream is in order: its last mark covers all of it
+    RC(join(g_side.done[0]));                      // the side stream is in order: its last two marks cover all of it
+    RC(join(g_side.done[1]));
     { PROF(PC_EMBED, TH * 12);
       RC(snx_embed_ln_bwd(dh, ids, F(p.tok_emb()), F(p.emb_norm()), G(p.tok_emb()), G(p.emb_norm()), T, H, d->ln_eps,
                           d->pad_id, st)); }

@@ -23,7 +23,6 @@ SIGNATURES = {
     "snx_cast_bf16": (I32, [P, P, I64, P]),
     "snx_cast_transpose_bf16": (I32, [P, P, I32, I32, P]),
     "snx_gemm_nt_bf16": (I32, [P, P, P, I32, I32, I32, P]),
-    "snx_gemm_nt256_bf16": (I32, [P, P, P, I32, I32, I32, P]),
     "snx_gemm_nt_resid": (I32, [P, P, P, P, I32, I32, I32, P]),
     "snx_gemm_tn_accum": (I32, [P, P, P, I32, I32, I32, P]),
     "snx_ln_fwd": (I32, [P, P, P, I32, I32, F32, P]),
@@ -43,6 +42,7 @@ SIGNATURES = {
     "snx_gemm_nt_geglu_fwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "snx_gemm_nt_geglu_bwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "snx_gemm_tn_accum_interleaved": (I32, [P, P, P, I32, I32, I32, P]),
+    "snx_gemm_tn_accum_group": (I32, [P, I32, I32, P]),
     "snx_cast_geglu_interleave": (I32, [P, P, P, I32, I32, P]),
     "snx_splade_head_scratch_bytes": (SZ, [I32, I32]),
     "snx_decoder_splade_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),

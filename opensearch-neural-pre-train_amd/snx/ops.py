@@ -64,18 +64,6 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return c
 
 
-def gemm_nt256(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """Same as gemm_nt on the 256x256 ping-pong kernel."""
-    _chk(a, BF16, "a"); _chk(b, BF16, "b")
-    M, K = a.shape
-    N, K2 = b.shape
-    if K != K2 or K % 64:
-        raise ValueError("gemm_nt256: bad K")
-    c = torch.empty((M, N), dtype=BF16, device=a.device)
-    check(fn("snx_gemm_nt256_bf16")(_p(a), _p(b), _p(c), M, N, K, _stream()), "snx_gemm_nt256_bf16")
-    return c
-
-
 def gemm_nt_resid(a: torch.Tensor, b: torch.Tensor, h_in: torch.Tensor) -> torch.Tensor:
     """h_out = h_in + bf16(A @ B^T)  (fp32 residual stream)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b")
@@ -154,6 +142,28 @@ def gemm_tn_accum_interleaved(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tenso
     M, N = dy.shape; K = x.shape[1]
     _chk(dw, torch.float32, "dw", (N, K))
     check(fn("snx_gemm_tn_accum_interleaved")(_p(dy), _p(x), _p(dw), M, N, K, _stream()), "snx_gemm_tn_accum_interleaved")
+
+
+class TnProblem(C.Structure):
+    _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32),
+                ("interleaved", C.c_int32), ("reserved", C.c_int32)]
+
+
+def gemm_tn_accum_group(problems) -> None:
+    """[(dy [M,N] bf16, x [M,K] bf16, dw [N,K] fp32, interleaved: bool)] (1..4 entries, same M):
+    dw += dy^T @ x for all of them in ONE launch (include/snx.h snx_gemm_tn_accum_group)."""
+    if not 1 <= len(problems) <= 4:
+        raise ValueError("gemm_tn_accum_group: 1..4 problems")
+    M = problems[0][0].shape[0]
+    arr = (TnProblem * len(problems))()
+    for i, (dy, x, dw, inter) in enumerate(problems):
+        _chk(dy, BF16, "dy"); _chk(x, BF16, "x")
+        if dy.shape[0] != M or x.shape[0] != M:
+            raise ValueError("gemm_tn_accum_group: all problems share the token dimension")
+        N, K = dy.shape[1], x.shape[1]
+        _chk(dw, torch.float32, "dw", (N, K))
+        arr[i] = TnProblem(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, K, int(bool(inter)), 0)
+    check(fn("snx_gemm_tn_accum_group")(arr, len(problems), M, _stream()), "snx_gemm_tn_accum_group")
 
 
 # ----------------------------------------------------------------------------- norms

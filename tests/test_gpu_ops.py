@@ -298,6 +298,29 @@ def test_gemm_tn_accum(dev, M, N, K):
     assert err < 1e-3 * max(1.0, ref.abs().max().item()), err
 
 
+def test_gemm_tn_group_equals_separate_launches(dev):
+    """The four weight gradients of one encoder layer in ONE grouped launch (different N, K, one of them with the
+    interleaved GeGLU column order) == four separate launches, up to the order of the fp32 atomic adds."""
+    ops = _ops()
+    M, H, I = 3000, 256, 384
+    g = torch.Generator().manual_seed(8)
+    mk = lambda r, c, s=0.1: (torch.randn(r, c, generator=g) * s).to(dev).to(BF16)   # noqa: E731
+    shapes = [(3 * H, H, False), (2 * I, H, True), (H, I, False), (H, H, False)]
+    probs, refs = [], []
+    for N, K, inter in shapes:
+        dy, x = mk(M, N), mk(M, K, 1.0)
+        dw = torch.randn(N, K, generator=g).to(dev)
+        ref = dw.clone()
+        (ops.gemm_tn_accum_interleaved if inter else ops.gemm_tn_accum)(dy, x, ref)
+        probs.append((dy, x, dw, inter))
+        refs.append(ref)
+    ops.gemm_tn_accum_group(probs)
+    for (dy, x, dw, inter), ref in zip(probs, refs):
+        assert torch.allclose(dw, ref, rtol=1e-4, atol=1e-3), float((dw - ref).abs().max())
+    with pytest.raises(ValueError):
+        ops.gemm_tn_accum_group(probs + probs[:1])
+
+
 def test_gemm_tn_layout(dev):
     """dY = shifted identity pattern: dW[n, :] must equal X[row(n), :] (catches n/k swaps)."""
     ops = _ops()
