@@ -40,11 +40,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 @pytest.mark.gpu
 def test_bench_under_torchrun_one_rank_over_rccl():
     """`--gpus N` launch path with N = 1: torch.distributed.run, nccl (= RCCL) process group, rank-0 broadcast,
-    bucketed gradient all-reduce overlapped with the last backward of each window (SNX_DIST_FORCE=1)."""
+    bucketed gradient all-reduce overlapped with the last backward of each window, and BASELINE config 4's
+    all-gather / reduce-scatter of the positive vectors (SNX_DIST_FORCE=1 issues them with one rank)."""
     env = dict(os.environ, SNX_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "1", "--steps", "8", "--warmup", "4", "--no-cpu-baseline", "--no-profile"],
+                        "--gpus", "1", "--steps", "8", "--warmup", "4", "--no-cpu-baseline", "--no-profile",
+                        "--cross-gpu-negatives"],     # config 4: all-gather of the positives + reduce-scatter backward
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]

@@ -515,8 +515,8 @@ def train_epoch_case(dev, mode):
     cos = num / ((den1 * den2) ** 0.5)
     rep.update({"update_cos": cos, "worst_mean_abs_err_over_lr": worst_mean, "worst_frac_err_gt_0.1lr": worst_frac})
     _report(f"train_epoch_{mode}", rep)
-    assert cos > 0.995, cos
-    assert worst_mean < 0.05 and worst_frac < 0.1, rep
+    assert cos > 0.995, cos                               # measured 0.9972
+    assert worst_mean < 0.03 and worst_frac < 0.03, rep   # measured 0.018 / 0.012
 
 
 @pytest.mark.parametrize("mode", ["native", "plain"])

@@ -37,6 +37,8 @@ x = rnd(M, H); w = rnd(H, H, scale=0.05); hin = torch.randn(M, H, device=dev)
 report("store  N=768 K=768", timeit(lambda: ops.gemm_nt(x, w)), 2.0 * M * H * H)
 x3 = rnd(M, 3 * H); w3 = rnd(H, 3 * H, scale=0.05)
 report("store  N=768 K=2304", timeit(lambda: ops.gemm_nt(x3, w3)), 2.0 * M * H * 3 * H)
+report("torch  N=768 K=2304", timeit(lambda: torch.matmul(x3, w3.t())), 2.0 * M * H * 3 * H)
+report("torch  N=768 K=768", timeit(lambda: torch.matmul(x, w.t())), 2.0 * M * H * H)
 report("resid  N=768 K=768", timeit(lambda: ops.gemm_nt_resid(x, w, hin)), 2.0 * M * H * H)
 y = rnd(M, I); wo = rnd(H, I, scale=0.05)
 report("resid  N=768 K=1152", timeit(lambda: ops.gemm_nt_resid(y, wo, hin)), 2.0 * M * H * I)

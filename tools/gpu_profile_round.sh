@@ -8,8 +8,8 @@ O=gpurun_out/prof_$R
 rm -rf $O; mkdir -p $O
 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
 python3 bench.py --d-len 512 --negatives 4 --margin-mse 0.5 --steps 16 --warmup 4 --no-cpu-baseline > $O/bench_cfg5_n1.json 2> $O/bench_cfg5.err || exit 1
-SNX_BWD_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $O/stats -o b -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-profile > $O/stats.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats -d $O/stats_overlap -o b -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-profile > $O/stats_overlap.log 2>&1 || exit 1
+SNX_BWD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-profile > $O/stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_overlap -o b -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-profile > $O/stats_overlap.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o f -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $O/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o w -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $O/pmc_write.log 2>&1 || exit 1
 F=$(find $O/pmc_fetch -name "f_results.db" | head -1); W=$(find $O/pmc_write -name "w_results.db" | head -1)
