@@ -299,12 +299,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       g.store_f32(dh + (long)t * H, lane);
       if (dh_bf16) g.store_bf16(dh_bf16 + (long)t * H, lane);
     } else if (MODE == 1) {
+      // The row goes through this wave's slice of `red` so that every atomic instruction adds 64 CONSECUTIVE
+      // floats (256 B: the shape the memory-side atomic units take at full rate) instead of 4 B at a 16-B stride.
+      float* mine = red[wave];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) *(f32x4*)(mine + (i * 64 + lane) * 4) = g.v[i];
       if (id != pad_id) {                                  // nn.Embedding(padding_idx): no grad to the pad row
         float* dst = gradE + id * (long)H;
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(dst + (i * 64 + lane) * 4 + e, g.v[i][e]);
+        for (int q = 0; q < 4 * NV; ++q) atomicAdd(dst + q * 64 + lane, mine[q * 64 + lane]);
       }
     } else {
 #pragma unroll
