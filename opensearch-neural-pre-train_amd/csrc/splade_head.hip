@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void splade_bwd_dw_kernel(const float* __restr
 // kernel below -- and with it dHd -- is the same in every run (two-run bit-compare).  Each of the
 // 16 waves owns a contiguous vocabulary range and keeps its own per-row counters; a wave's slots for a row
 // start after those of the waves before it, and inside one 64-entry step lanes that hit the same row are
-// ranked by lane id (wave-uniform loop over the distinct rows of the step: ballot + popcount, no atomics
+// ranked by lane id (bitonic sort of (row, lane) across the wave + segment heads by ballot: no atomics
 // whose arrival order could vary).  DET = false (rows > 1024: the per-wave tables no longer fit) falls back
 // to first-come slots from an LDS atomic counter.
 template <bool DET>
@@ -375,17 +375,40 @@ __global__ __launch_bounds__(1024) void splade_bucket_kernel(const float* __rest
       if (v < ve) { key = ks[v]; c = splade_coef(gs[v], key); }
       const int row = (int)(0xFFFFu - (key & 0xFFFFu));
       const bool act = c != 0.f && row < rows;
-      unsigned long long todo = __ballot(act);
-      int slot = 0;
-      while (todo) {                                                  // one pass per distinct row of this step
-        const int leader = __ffsll((long long)todo) - 1;
-        const int r = __builtin_amdgcn_readlane(row, leader);
-        const unsigned long long same = __ballot(act && row == r);
-        const int base = off[r] + mine[r];
-        if (act && row == r) slot = base + __popcll(same & ((1ull << lane) - 1ull));
-        if (lane == leader) mine[r] += __popcll(same);
-        todo &= ~same;
+      // rank of every entry among the entries of this step that hit the same row, lower lane (= lower vocabulary
+      // id) first: bitonic sort of (row << 6 | lane) across the wave, then position minus position of the
+      // segment head.  No atomics whose arrival order could vary, and no LDS round trip per distinct row.
+      // (idle lanes sort to the end with their own lane id in the low bits, so that the hand-back below is a bijection)
+      uint32_t sk = act ? (((uint32_t)row << 6) | (uint32_t)lane) : (0xFFFFFFC0u | (uint32_t)lane);
+#pragma unroll
+      for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const uint32_t other = (uint32_t)__shfl_xor((int)sk, j, 64);
+          const bool up = ((lane & k) == 0) || k == 64;               // ascending overall
+          const bool lower = (lane & j) == 0;
+          const uint32_t mn = sk < other ? sk : other, mx = sk < other ? other : sk;
+          sk = (lower == up) ? mn : mx;
+        }
+      const bool sact = sk < 0xFFFFFFC0u;                             // sorted position `lane` holds a live entry
+      const int srow = (int)(sk >> 6), src = (int)(sk & 63u);
+      const int prev_row = __shfl_up(srow, 1, 64);
+      const bool head = sact && (lane == 0 || prev_row != srow);
+      const unsigned long long heads = __ballot(head), live = __ballot(sact);
+      // position of this segment's head = highest head bit at or below this lane; its end = next head bit or the live count
+      const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+      const int hpos = 63 - __builtin_clzll(below | 1ull);
+      const unsigned long long above = heads & ~((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+      const int nlive = __popcll(live);
+      const int epos = above ? (__ffsll((long long)above) - 1) : nlive;
+      int slot_sorted = 0;
+      if (sact) {
+        const int base = off[srow] + mine[srow];
+        slot_sorted = base + (lane - hpos);
       }
+      if (head) mine[srow] += epos - hpos;                            // one writer per row and step
+      // hand every slot back to the lane that owns the entry (sorted position -> source lane)
+      const int slot = __builtin_amdgcn_ds_permute(src << 2, sact ? slot_sorted : 0);
       if (act) { lv[slot] = v; lc[slot] = c; }
     }
   } else {
