@@ -82,9 +82,10 @@ class BucketedGradSync:
     keep all 7 links busy, so the default is 4 buckets of ~120-230 MB rather than DDP's 25 MB."""
 
     def __init__(self, device, n_buckets: int = 4):
-        self.device = device
+        self.device = torch.device(device)
         self.n_buckets = max(1, int(n_buckets))
-        self.stream = exchange_stream(device)
+        # CPU tensors (gloo, host-logic tests) have no streams: the collectives then simply run in program order
+        self.stream = exchange_stream(self.device) if self.device.type == "cuda" else None
         self.armed = False
         self.pending = False
         self.slices: List[Tuple[int, int]] = []          # what the last armed backward reduced (tests)
@@ -105,8 +106,12 @@ class BucketedGradSync:
             self.slices = []
 
     def reduce_slice(self, flat: torch.Tensor, lo: int, hi: int) -> None:
-        with torch.cuda.stream(self.stream):
-            dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.AVG)
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.AVG)
+        else:                                            # gloo has no AVG
+            dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM)
+            flat[lo:hi].div_(world())
         self.slices.append((lo, hi))
 
     def finished_backward(self) -> None:
@@ -117,8 +122,9 @@ class BucketedGradSync:
         """Compute stream waits for the exchange; False when no overlapped exchange was done."""
         if not self.pending:
             return False
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
-        flat.record_stream(self.stream)
+        if self.stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            flat.record_stream(self.stream)
         self.pending = False
         return True
 

@@ -259,7 +259,34 @@ def _dist_worker(rank, world, port, ret):
     ok2 = torch.allclose(p.grad, Ps[rank].grad, atol=1e-6) and pall.shape == (world * B, V)
     from src.train.core import ddp_trainer as T
     ok3 = T.is_main_process() == (rank == 0)
-    ret[rank] = (bool(ok1), bool(ok2), bool(ok3))
+    # (3) the bucketed exchange that overlaps the backward: drive BucketedGradSync exactly as
+    # EncoderRuntime.backward_impl does (unit ranges -> finished flat slices -> one all-reduce each) on a flat
+    # gradient laid out like a 6-layer model's; every element must come out as the mean over ranks, reduced once
+    from snx.dist import BucketedGradSync
+    from snx.encoder import EncoderGeometry, EncoderRuntime
+    geom = EncoderGeometry(num_hidden_layers=6, vocab_size=100, hidden_size=256, intermediate_size=128, pad_token_id=99)
+    H, I, V, L = 256, 128, 100, 6
+    sizes = [V * H, H]
+    for l in range(L):
+        sizes += ([H] if l else []) + [3 * H * H, H * H, H, 2 * I * H, H * I]
+    sizes += [H, H * H, H, V]
+    rt = EncoderRuntime.__new__(EncoderRuntime)
+    rt.geom = geom
+    rt.params = [torch.empty(n) for n in sizes]
+    total = sum(sizes)
+    flat = torch.arange(total, dtype=torch.float32) * (rank + 1)
+    gs = BucketedGradSync(torch.device("cpu"), 3)
+    gs.arm(True)
+    ok4 = gs.armed
+    for ub, ue in gs.unit_ranges(L + 2):
+        for lo, hi in rt.unit_param_range(ub, ue):
+            gs.reduce_slice(flat, lo, hi)
+    gs.finished_backward()
+    cov = sorted(gs.slices)
+    ok4 = ok4 and cov[0][0] == 0 and cov[-1][1] == total and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
+    ok4 = ok4 and gs.wait(flat) and not gs.wait(flat)
+    ok4 = ok4 and torch.allclose(flat, torch.arange(total, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
+    ret[rank] = (bool(ok1), bool(ok2), bool(ok3), bool(ok4))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -270,4 +297,4 @@ def test_world_size_2_collectives_gloo():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_dist_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
-    assert dict(ret) == {0: (True, True, True), 1: (True, True, True)}
+    assert dict(ret) == {0: (True, True, True, True), 1: (True, True, True, True)}
