@@ -318,7 +318,7 @@ def flops_loss(w: torch.Tensor) -> torch.Tensor:
 
 
 def loss_v33(lc: LossConfig, anchor, positive, negative, global_step: int = 0,
-             teacher_pos_scores=None, teacher_neg_scores=None, mode: str = "fp32"):
+             teacher_pos_scores=None, teacher_neg_scores=None, mode: str = "fp32", teacher_scores=None):
     """SPLADELossV33.forward (ref:losses.py:183-297) -> (loss, dict of python floats).
     ``mode="bf16"`` rounds the two operands of the in-batch ``torch.mm`` to bf16 (and its
     result to bf16), as autocast does on the reference GPU path (ref:losses.py:155)."""
@@ -341,6 +341,16 @@ def loss_v33(lc: LossConfig, anchor, positive, negative, global_step: int = 0,
     ld = lambda_schedule(global_step, lc.lambda_d, lc.flops_warmup_steps, lc.lambda_initial_ratio)
     ln = lambda_schedule(global_step, lam_neg_target, lc.flops_warmup_steps, lc.lambda_initial_ratio)
     loss = infonce + lq * fq + ld * fd + ln * fneg
+    kd = torch.tensor(0.0)
+    if lc.lambda_kd > 0 and teacher_scores is not None:                         # ref:losses.py:239-253
+        if mode == "bf16":
+            student = (anchor.to(BF16).float() @ positive.to(BF16).float().t()).to(BF16).float()
+        else:
+            student = anchor @ positive.t()
+        student = student / lc.kd_temperature
+        kd = F.kl_div(F.log_softmax(student, dim=-1), F.softmax(teacher_scores / lc.kd_temperature, dim=-1),
+                      reduction="batchmean")
+        loss = loss + lc.lambda_kd * kd
     mmse = torch.tensor(0.0)
     if lc.lambda_margin_mse > 0 and teacher_pos_scores is not None and teacher_neg_scores is not None:
         sp = (anchor * positive).sum(-1)
@@ -356,7 +366,7 @@ def loss_v33(lc: LossConfig, anchor, positive, negative, global_step: int = 0,
         nzq = (anchor > 0).float().sum(-1).mean()
         nzd = (positive > 0).float().sum(-1).mean()
     d = {"infonce": infonce.item(), "flops_q": fq.item(), "flops_d": fd.item(), "flops_neg": fneg.item(),
-         "lambda_q": lq, "lambda_d": ld, "lambda_neg": ln, "kd": 0.0, "margin_mse": float(mmse.item()),
+         "lambda_q": lq, "lambda_d": ld, "lambda_neg": ln, "kd": float(kd.item()), "margin_mse": float(mmse.item()),
          "nonzero_q": nzq.item(), "nonzero_d": nzd.item()}
     return loss, d
 

@@ -210,6 +210,28 @@ def test_loss_kernels_vs_golden_g4(dev):
         assert lf.get_avg_nonzero()[0] == pytest.approx(c["avg_nonzero"][0], rel=1e-5)
 
 
+def test_loss_kd_branch_vs_golden_g9(dev):
+    """KL-distillation branch of SPLADELossV33 (ref:src/model/losses.py:239-253; never fed by the V33 trainer):
+    device loss kernels + the KD term vs the reference's own outputs, fp32 operands."""
+    from src.model.losses import SPLADELossV33
+    z = np.load(os.path.join(G, "g9_loss_kd.npz"))
+    cases = json.load(open(os.path.join(G, "g9_loss_kd.json")))
+    for c in cases:
+        pre = f"c{c['id']}::"
+        a, p, n = (torch.from_numpy(z[pre + x]).to(dev).requires_grad_(True) for x in "apn")
+        lf = SPLADELossV33(**c["loss_kwargs"]).to(dev)
+        loss, d = lf(anchor_repr=a, positive_repr=p, negative_repr=n, global_step=c["step"],
+                     teacher_scores=torch.from_numpy(z[pre + "ts"]).to(dev),
+                     teacher_pos_scores=torch.from_numpy(z[pre + "tp"]).to(dev),
+                     teacher_neg_scores=torch.from_numpy(z[pre + "tn"]).to(dev))
+        assert float(loss) == pytest.approx(c["loss"], rel=2e-5), c["id"]
+        for key, v in c["loss_dict"].items():
+            assert float(d[key]) == pytest.approx(v, rel=2e-5, abs=1e-6), (c["id"], key)
+        loss.backward()
+        for x, t in zip("apn", (a, p, n)):
+            np.testing.assert_allclose(t.grad.cpu().numpy(), z[pre + "d" + x], atol=2e-6, rtol=5e-4)
+
+
 def test_loss_cross_rank_identity(dev):
     """config-4 extension: anchors of `rank` against all-gathered positives == the oracle identity."""
     from oracle import splade_oracle as O

@@ -250,3 +250,22 @@ def test_g6_encode_postprocess_matches_reference_encode_batch():
             got = O.encode_postprocess(rep_row, fx["tokens"], fx["special"], top_k)
             assert [t for t, _ in got] == [t for t, _ in want], (k,)
             assert [w for _, w in got] == [w for _, w in want]
+
+
+def test_g9_kd_branch_matches_reference():
+    """KL-distillation branch (ref:src/model/losses.py:239-253) of the loss, with MarginMSE on for half the cases."""
+    z = _npz("g9_loss_kd.npz")
+    cases = json.load(open(os.path.join(G, "g9_loss_kd.json")))
+    assert len(cases) == 6 and all(c["loss_dict"]["kd"] > 0 for c in cases)
+    for c in cases:
+        pre = f"c{c['id']}::"
+        a, p, n = (_t(z[pre + x]).clone().requires_grad_(True) for x in "apn")
+        lc = O.LossConfig(**c["loss_kwargs"])
+        loss, d = O.loss_v33(lc, a, p, n, c["step"], _t(z[pre + "tp"]), _t(z[pre + "tn"]), "fp32",
+                             teacher_scores=_t(z[pre + "ts"]))
+        assert loss.item() == pytest.approx(c["loss"], rel=2e-5)
+        for key, v in c["loss_dict"].items():
+            assert d[key] == pytest.approx(v, rel=5e-5, abs=1e-6), (c["id"], key)
+        loss.backward()
+        for x, t in zip("apn", (a, p, n)):
+            np.testing.assert_allclose(t.grad.numpy(), z[pre + "d" + x], atol=2e-6, rtol=5e-4)

@@ -18,7 +18,7 @@ reference source is copied.
 Fixtures: g1 tiny fwd/bwd (+g6 edge rows), g2 tiny train_epoch (1-proc and
 2-proc gloo DDP), g3 full-size fwd/bwd summaries, g4 loss-only vectors, g5 collator layout,
 g6 inference post-processing, g7 BASELINE config 5 (d512, k=4, MarginMSE) at full size, g8 the g3 batch
-with an unsaturated InfoNCE.
+with an unsaturated InfoNCE, g9 the loss's KL-distillation branch.
 """
 from __future__ import annotations
 
@@ -495,6 +495,43 @@ def g6():
     json.dump({"V": V, "tokens": tokens, "special": special, "rep": rep.tolist(), "cases": cases},
               open(os.path.join(OUT, "g6_encode_topk.json"), "w"))
     print("g6 ok", {k: [len(d) for d in v] for k, v in cases.items()})
+
+
+def g9():
+    """The KL-distillation branch of SPLADELossV33 (ref:src/model/losses.py:239-253: softmax(teacher / T) vs
+    log_softmax(q p^T / T), batchmean) -- inactive in the V33 trainer (it never passes `teacher_scores`,
+    ref:train_v33_ddp.py:353-360) but part of the class API: loss, terms and input gradients with lambda_kd > 0."""
+    gen = torch.Generator().manual_seed(909)
+    cases, arrs = [], {}
+    ci = 0
+    for B, V, k in ((4, 512, 1), (64, 128, 1), (8, 300, 4)):
+        for lkd, kT in ((0.3, 1.0), (1.0, 2.5)):
+            lkw = dict(lambda_q=0.01, lambda_d=0.003, temperature=1.0, flops_warmup_steps=100,
+                       lambda_initial_ratio=0.1, lambda_kd=lkd, kd_temperature=kT,
+                       lambda_margin_mse=0.5 if ci % 2 else 0.0)
+
+            def sp(*shape):
+                x = torch.rand(*shape, generator=gen)
+                return (torch.relu(x - 0.6) * 3.0).requires_grad_(True)
+            a, p = sp(B, V), sp(B, V)
+            n = sp(B, k, V) if k > 1 else sp(B, V)
+            ts = 4.0 * torch.rand(B, B, generator=gen)
+            tp = 0.5 + 0.5 * torch.rand(B, generator=gen)
+            tn = 0.6 * torch.rand(B, k, generator=gen) if k > 1 else 0.6 * torch.rand(B, generator=gen)
+            lf = ref_loss_module(**lkw)
+            loss, d = lf(anchor_repr=a, positive_repr=p, negative_repr=n, global_step=40, teacher_scores=ts,
+                         teacher_pos_scores=tp, teacher_neg_scores=tn)
+            loss.backward()
+            pre = f"c{ci}::"
+            arrs.update({pre + "a": np_(a), pre + "p": np_(p), pre + "n": np_(n), pre + "ts": np_(ts),
+                         pre + "tp": np_(tp), pre + "tn": np_(tn), pre + "da": np_(a.grad), pre + "dp": np_(p.grad),
+                         pre + "dn": np_(n.grad)})
+            cases.append({"id": ci, "B": B, "V": V, "k": k, "step": 40, "loss_kwargs": lkw,
+                          "loss": float(loss.item()), "loss_dict": d})
+            ci += 1
+    np.savez_compressed(os.path.join(OUT, "g9_loss_kd.npz"), **arrs)
+    json.dump(cases, open(os.path.join(OUT, "g9_loss_kd.json"), "w"), indent=1)
+    print("g9 cases", len(cases), [c["loss_dict"]["kd"] for c in cases])
 
 
 if __name__ == "__main__":
