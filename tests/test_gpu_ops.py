@@ -372,7 +372,10 @@ def test_attention_bwd(dev, S, window):
         assert got[~valid][:, heads * 64:].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("B,S,V,H", [(3, 64, 1000, 256), (4, 256, 3000, 768), (2, 200, 640, 256)])
+# (2, 1024, ...): vocabulary-ordered buckets with > 64 KiB of LDS; (1, 1100, ...): beyond 1024 rows the per-wave slot
+# tables no longer fit and the bucket pass falls back to first-come slots; (2, 512, 50000, 768): config-5 documents
+@pytest.mark.parametrize("B,S,V,H", [(3, 64, 1000, 256), (4, 256, 3000, 768), (2, 200, 640, 256), (2, 1024, 700, 256),
+                                     (1, 1100, 512, 256), (2, 512, 50000, 768)])
 def test_splade_bwd(dev, B, S, V, H):
     ops = _ops()
     from snx._lib import fn, check
