@@ -51,6 +51,22 @@ def test_shape_validation_happens_on_the_host():
     assert fn("snx_model_workspace_bytes")(C.byref(d), 64 * 256, 64, 1) > fn("snx_model_workspace_bytes")(C.byref(d), 64 * 256, 64, 0)
     bad = EncoderGeometry(hidden_size=512, num_attention_heads=16).desc()            # head_dim 32
     assert fn("snx_param_count")(C.byref(bad)) == -1
+    # grouped weight-gradient GEMM: 1..4 problems, N and K multiples of 128, non-null operands
+    from snx.ops import TnProblem
+    ok = (TnProblem * 2)(TnProblem(16, 16, 16, 256, 128, 0, 0), TnProblem(16, 16, 16, 128, 128, 1, 0))
+    assert fn("snx_gemm_tn_accum_group")(ok, 0, 64, None) == -3
+    assert fn("snx_gemm_tn_accum_group")(ok, 5, 64, None) == -3
+    assert fn("snx_gemm_tn_accum_group")(None, 1, 64, None) == -3
+    odd = (TnProblem * 1)(TnProblem(16, 16, 16, 100, 128, 0, 0))
+    assert fn("snx_gemm_tn_accum_group")(odd, 1, 64, None) == -2
+    nul = (TnProblem * 1)(TnProblem(0, 16, 16, 128, 128, 0, 0))
+    assert fn("snx_gemm_tn_accum_group")(nul, 1, 64, None) == -3
+    # backward in unit ranges: the range must lie inside [0, layers + 2) and be non-empty
+    nine = [one] * 14
+    L = d.layers
+    for ub, ue, want in ((0, L + 3, -3), (-1, 2, -3), (3, 3, -3), (5, 2, -3)):
+        assert fn("snx_model_backward_units")(C.byref(d), *nine[:12], None, 64, 1, 64, ub, ue, None, None) == want, (ub, ue)
+    assert fn("snx_model_backward_units")(C.byref(d), None, *nine[:11], None, 64, 1, 64, 0, L + 2, None, None) == -3
 
 
 def test_product_path_has_no_cpu_fallback():
