@@ -49,7 +49,6 @@ def test_export_loads_in_stock_transformers_and_matches_oracle(tmp_path):
     sd = hf.state_dict()
     ours = m.model.state_dict()
     assert set(sd.keys()) == set(ours.keys()) and len(sd) == len(ours)
-    assert len(sd) == 4 + 2 + 1 + 6 * GEOM["num_hidden_layers"] - 1 + 1 - 0 or True   # counted below for 22 layers
     assert sd["decoder.weight"].data_ptr() == sd["model.embeddings.tok_embeddings.weight"].data_ptr()
     for k in ours:
         assert torch.equal(sd[k], ours[k].detach()), k
