@@ -34,6 +34,19 @@ struct EpiArgs {
   const bf16_t* U;           // GEGLU_BWD: u [M, 2N] interleaved
 };
 
+#ifdef SNX_GEMM_TRACE
+// Diagnostics build only (-DSNX_GEMM_TRACE, tools/gpu_gemm_trace.py): wave 0 of every workgroup records the
+// constant-rate clock at entry, after the K loop, after the last store is issued and after the stores have
+// left the wave, plus HW_ID / XCC_ID, so that the interleaving of the two workgroups of a CU can be drawn.
+__device__ unsigned long long* g_trace = nullptr;
+extern "C" int snx_gemm_trace_set(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf));
+}
+#define TRACE_T(k) if (threadIdx.x == 0 && g_trace) tr[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define TRACE_T(k)
+#endif
+
 __device__ __forceinline__ bf16x4 pack4(const f32x4 v) { return (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; }
 
 // ---- coalesced epilogue -----------------------------------------------------------------------
@@ -72,6 +85,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_kernel(
   static_assert(Core::WTN == 64 && Core::WTM == 64, "epilogues assume a 64x64 wave tile");
   static_assert(Core::LDS_BYTES >= WAVES_M * WAVES_N * 16384, "16 KiB of staging per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef SNX_GEMM_TRACE
+  unsigned long long tr[4] = {0, 0, 0, 0};
+  struct TraceOut {
+    unsigned long long* tr;
+    __device__ ~TraceOut() {
+      if (threadIdx.x == 0 && g_trace) {
+        __builtin_amdgcn_s_waitcnt(0);
+        tr[3] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = g_trace + 8l * blockIdx.x;
+        o[0] = tr[0]; o[1] = tr[1]; o[2] = tr[2]; o[3] = tr[3];
+        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+      }
+    }
+  } trace_out{tr};
+#endif
+  TRACE_T(0);
   int tile_m, tile_n;
   tile_of(order, xcd_remap(blockIdx.x, ntiles), tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -146,6 +176,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_kernel(
     if (MID) Core::template mainloop_mid<true>(A, K, lm, M, B, K, ln, N, K, smem, acc, pre_issue, npre16, early);
     else Core::template mainloop<true>(A, K, lm, M, B, K, ln, N, K, smem, acc, pre_issue, npre16, early);
   }
+  TRACE_T(1);
   if (dbg & 2) {                                     // dbg bit 1: skip the epilogue (keep the accumulators live)
     float sum = 0.f;
 #pragma unroll
@@ -256,7 +287,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_kernel(
         if (row < M) *(bf16x8*)(e.Y + (long)row * (N >> 1) + ycol) = v;
       }
     }
-  }
+  }  TRACE_T(2);
 }
 
 template <int EPI>
