@@ -19,6 +19,7 @@
 // 4-stage ring (571), persistent workgroups with cross-tile prefetch (neutral), stream-K for dW.
 // Two independent 4-wave workgroups per CU with one barrier per 64-deep K-step win.
 #include "gemm_core.h"
+#include "gemm_tn.h"
 #include "snx.h"
 
 enum { EPI_STORE_BF16 = 0, EPI_RESID_F32 = 1, EPI_ROPE = 2, EPI_GEGLU_FWD = 3, EPI_GEGLU_BWD = 4 };
@@ -387,8 +388,6 @@ extern "C" int snx_gemm_nt_geglu_bwd(const void* A, const void* B, const void* U
 // ------------------------------------------------------------------------------------------
 __device__ uint4 snx_zero_page[16];   // 256 B of zeros: DMA source for token rows past M
 
-__device__ __forceinline__ int tn_chunk(int row, int ch) { return ch ^ (((row & 3) << 2) | ((row >> 2) & 3)); }
-
 // stage 64 token rows x 128 columns (bf16) of G (leading dim ld), rows m0.., columns c0..
 __device__ __forceinline__ void tn_stage(const bf16_t* __restrict__ G, long ld, int m0, int M, int c0, char* lds,
                                          int wave, int lane) {
@@ -402,33 +401,6 @@ __device__ __forceinline__ void tn_stage(const bf16_t* __restrict__ G, long ld, 
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + ci * 1024), 16, 0, 0);
   }
 }
-
-// fragment for MFMA row/col index (cbase + lane&15), contraction elements m = mb + 8g + 0..7
-__device__ __forceinline__ bf16x8 tn_frag(const char* tile, int mb, int cbase, int lane) {
-  const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int ch = (cbase >> 3) + (tp >> 1);
-  const int r0 = mb + 8 * g + tq, r1 = r0 + 4;
-  const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-      (__attribute__((address_space(3))) bf16x4*)(tile + r0 * 256 + tn_chunk(r0, ch) * 16 + (tp & 1) * 8));
-  const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-      (__attribute__((address_space(3))) bf16x4*)(tile + r1 * 256 + tn_chunk(r1, ch) * 16 + (tp & 1) * 8));
-  return (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-}
-
-// Up to SNX_TN_MAX_GROUP weight-gradient problems that share the token dimension M (the four Linears of one
-// encoder layer) run as ONE launch: their output tiles are concatenated, so that tiles x splits can fill whole
-// rounds of the 512 resident workgroups (a single Wqkv / Wi problem has 108 tiles: 4 splits = 432 workgroups,
-// 84 % of one round; the layer's 306 tiles x 5 splits = 1530 = 99.6 % of three rounds) and only the last
-// round's float atomics are exposed.
-#define SNX_TN_MAX_GROUP 4
-struct TnGroup {
-  const bf16_t* dY[SNX_TN_MAX_GROUP];
-  const bf16_t* X[SNX_TN_MAX_GROUP];
-  float* dW[SNX_TN_MAX_GROUP];
-  int N[SNX_TN_MAX_GROUP], K[SNX_TN_MAX_GROUP], inter[SNX_TN_MAX_GROUP];
-  int tile_end[SNX_TN_MAX_GROUP];       // running tile count after problem p
-  int nprob;
-};
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnGroup grp, int M, int ntiles, int rows_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -534,6 +506,10 @@ static int tn_pick_splits(int tiles, int M) {
 }
 
 static int launch_tn_group(const TnGroup& g, int M, hipStream_t st) {
+  // long token ranges: the 256x256 persistent form (gemm_tn256.hip); SNX_TN256=0 keeps the 128x128 kernel
+  static const int tn256 = getenv("SNX_TN256") ? atoi(getenv("SNX_TN256")) : 1;
+  static const int tn256_min_m = getenv("SNX_TN256_MIN_M") ? atoi(getenv("SNX_TN256_MIN_M")) : 8192;
+  if (tn256 && M >= tn256_min_m) return snx_launch_tn256(g, M, st);
   const int tiles = g.tile_end[g.nprob - 1];
   int splits = tn_pick_splits(tiles, M);
   int rows = cdiv(M, splits);

@@ -24,6 +24,10 @@ def fl(ps): return sum(2.0 * M * p[0].shape[1] * p[1].shape[1] for p in ps)
 def rep(name, ps):
     us = timeit(lambda: ops.gemm_tn_accum_group(ps)); print(f"{name:22s} {us:8.1f} us {fl(ps) / us / 1e6:7.1f} TFLOP/s", flush=True)
 rep("group of 4", probs)
+def torch_tn(ps):
+    for dy, x, dw, _ in ps: torch.matmul(dy.t(), x)
+us = timeit(lambda: torch_tn(probs)); print(f"{'torch dY^T X (bf16 out) x4':22s} {us:8.1f} us {fl(probs) / us / 1e6:7.1f} TFLOP/s", flush=True)
+if os.environ.get("QUICK"): sys.exit(0)
 rep("pair 0+1", probs[:2])
 rep("pair 2+3", probs[2:])
 for i, p in enumerate(probs):
