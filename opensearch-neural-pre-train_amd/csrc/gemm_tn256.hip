@@ -12,15 +12,15 @@
 //     slot:        s         s+1       s+2       s+3
 //     waves 0-3:   LOAD p    MFMA p    LOAD p+1  MFMA p+1
 //     waves 4-7:   MFMA p-1  LOAD p    MFMA p    LOAD p+1            (every slot ends in one s_barrier)
-// A K-step (64 tokens) is four phases, one 64x32 quadrant of the wave tile each (16 MFMAs).  Its operands are four
-// 16 KiB sub-tiles (gemm_tn.h image): 0 = dY columns {0-63, 128-191} (the upper 64 rows of both wave rows),
-// 3 = dY columns {64-127, 192-255}, 1 / 2 = X columns {64w + 0-31} / {64w + 32-63} of the four wave columns.
-// Phase 0 reads sub-tiles 0 and 1, phase 1 reads 2, phase 2 reads 3, phase 3 nothing.  A sub-tile's LDS region is
-// refilled for K-step t+2 in the phase AFTER its last read (two stages of 64 KiB hold t, t+1 and the parts of t+2
-// already requested): the stream of sub-tile requests runs 7 ahead of the reads, one request (2 DMA instructions
-// per wave) per phase, and every LOAD segment ends with the COUNTED s_waitcnt vmcnt(10): all but the five newest
-// requests have landed.  A request therefore has 1.5 K-steps to come back from HBM (the operands of a weight
-// gradient are a layer old: nothing of them is in L2).
+// A K-step (64 tokens) is two phases, one 64x64 half of the wave tile each (32 MFMAs = 512 matrix-pipe cycles,
+// long enough to cover the partner's LOAD segment).  Its operands are four 16 KiB sub-tiles (gemm_tn.h image):
+// 0 = dY columns {0-63, 128-191} (the upper 64 rows of both wave rows), 3 = dY columns {64-127, 192-255},
+// 1 / 2 = X columns {64w + 0-31} / {64w + 32-63} of the four wave columns.  Phase 0 reads sub-tiles 0, 1, 2,
+// phase 1 reads 3.  A sub-tile's LDS region is refilled for K-step t+2 in the phase AFTER its last read (two
+// stages of 64 KiB hold t, t+1 and the parts of t+2 already requested): 0, 1, 2 in phase 1 of t, 3 in phase 0 of
+// t+1, 2 DMA instructions per wave each, and every LOAD segment ends with the COUNTED s_waitcnt vmcnt(8): all but
+// the four newest requests have landed.  A request has one K-step to come back from HBM (the operands of a
+// weight gradient are a layer old: nothing of them is in L2).
 //   RAW: a sub-tile is read one barrier after the covering wait of BOTH wave groups.
 //   WAR: a refill is issued one barrier after both groups' reads, and every LOAD segment ends with lgkmcnt(0).
 //
@@ -89,21 +89,53 @@ __device__ __forceinline__ Tile decode(const TnGroup& g, int tile) {
   return t;
 }
 
-// request sub-tile C of the K-step starting at token tok0 into `stage`
-template <int C>
-__device__ __forceinline__ void dma_sub(const Tile& t, int tok0, int M, char* stage, int wave, int lane) {
-  constexpr bool isA = (C == 0 || C == 3);
+// Per-lane byte offsets of the two DMA instructions a wave issues per sub-tile: (token row) * ld + column, from the
+// K-step's first token row and the tile's first column.  Sub-tiles 3 / 2 are sub-tiles 0 / 1 shifted by 64 / 32
+// columns (added to the wave-uniform base).  Columns past the matrix edge (K = 1152 -> half a tile) are
+// clamped into it: they only feed accumulators that are never written back.
+struct LaneOff { unsigned a[2], b[2]; };
+
+__device__ __forceinline__ LaneOff lane_offsets(const Tile& t, int wave, int lane) {
+  LaneOff o;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int ci = i * 8 + wave;                     // 4-row group written by this wave instruction
-    const int row = ci * 4 + (lane >> 4);
+    const int row = (i * 8 + wave) * 4 + (lane >> 4);
     const int lc = tn_chunk(row, lane & 15) * 8;     // first of the 8 local columns held at this lane's slot
-    const int gcol = isA ? (lc >> 6) * 128 + (C == 3 ? 64 : 0) + (lc & 63) : (lc >> 5) * 64 + (C == 2 ? 32 : 0) + (lc & 31);
-    const int tok = tok0 + row;
-    const bool ok = tok < M && (isA ? t.n0 + gcol < t.N : t.k0 + gcol < t.K);
-    const bf16_t* src = ok ? (isA ? t.dy + (long)tok * t.N : t.x + (long)tok * t.K) + gcol
-                           : (const bf16_t*)zero_page256 + (lane & 15) * 8;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + C * SUB + ci * 1024), 16, 0, 0);
+    int ca = (lc >> 6) * 128 + (lc & 63), cb = (lc >> 5) * 64 + (lc & 31);
+    ca = min(ca, t.N - t.n0 - 72);                   // ca + 64 + 8 <= N - n0
+    cb = min(cb, t.K - t.k0 - 40);
+    o.a[i] = (unsigned)(row * t.N + ca) * 2u;
+    o.b[i] = (unsigned)(row * t.K + cb) * 2u;
+  }
+  return o;
+}
+
+// request sub-tile C of the K-step starting at token tok0 into `stage` (tok0 + 64 <= M)
+template <int C>
+__device__ __forceinline__ void dma_sub(const Tile& t, const LaneOff& o, int tok0, char* stage, int wave) {
+  constexpr bool isA = (C == 0 || C == 3);
+  // (the instruction's immediate offset would move the LDS address too: the column shift goes into the base)
+  const char* base = isA ? (const char*)(t.dy + (long)tok0 * t.N + (C == 3 ? 64 : 0))
+                         : (const char*)(t.x + (long)tok0 * t.K + (C == 2 ? 32 : 0));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const char* src = base + (isA ? o.a[i] : o.b[i]);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + C * SUB + (i * 8 + wave) * 1024), 16, 0, 0);
+  }
+}
+
+// the K-step that holds the last, partly filled 64 token rows of the matrix: rows past M read zeros
+template <int C>
+__device__ __forceinline__ void dma_sub_tail(const Tile& t, const LaneOff& o, int tok0, int M, char* stage, int wave,
+                                             int lane) {
+  constexpr bool isA = (C == 0 || C == 3);
+  const char* base = isA ? (const char*)(t.dy + (long)tok0 * t.N) : (const char*)(t.x + (long)tok0 * t.K);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 8 + wave) * 4 + (lane >> 4);
+    const char* src = tok0 + row < M ? base + (isA ? o.a[i] : o.b[i]) + (C == 3 ? 128 : C == 2 ? 64 : 0)
+                                     : (const char*)zero_page256 + (lane & 15) * 16;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + C * SUB + (i * 8 + wave) * 1024), 16, 0, 0);
   }
 }
 
@@ -140,6 +172,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnGroup grp, int M, Sch
   int cp_it = ld_it;
   cp_item = ld_item;
   Tile ld_tile = decode(grp, ld_item.tile), cp_tile = ld_tile;
+  LaneOff ld_off = lane_offsets(ld_tile, wave, lane);
   int ld_s = ld_item.sb, cp_s = cp_item.sb;
   int ld_par = 0;
   bool ld_ok = true;
@@ -150,17 +183,22 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnGroup grp, int M, Sch
       ld_ok = ld_it >= 0;
       if (ld_ok) {
         ld_tile = decode(grp, ld_item.tile);
+        ld_off = lane_offsets(ld_tile, wave, lane);
         ld_s = ld_item.sb;
       }
     }
   };
-#define REQ(C)                                                                        \
-  do {                                                                                \
-    if (ld_ok && !(sch.dbg & 2)) dma_sub<C>(ld_tile, (sch.dbg & 4) ? 0 : ld_s * 64, M, smem + ld_par * STAGE, wave, lane);  \
+#define REQ(C)                                                                                          \
+  do {                                                                                                  \
+    if (ld_ok && !(sch.dbg & 2)) {                                                                      \
+      const int tok0 = (sch.dbg & 4) ? 0 : ld_s * 64;                                                   \
+      if (tok0 + 64 <= M) dma_sub<C>(ld_tile, ld_off, tok0, smem + ld_par * STAGE, wave);               \
+      else dma_sub_tail<C>(ld_tile, ld_off, tok0, M, smem + ld_par * STAGE, wave, lane);                \
+    }                                                                                                   \
   } while (0)
 #define LOAD_END()                       \
   do {                                   \
-    if (ld_ok) WAIT_VM(10);              \
+    if (ld_ok) WAIT_VM(8);               \
     else WAIT_VM(0);                     \
     WAIT_LGKM0();                        \
     BARRIER();                           \
@@ -170,7 +208,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnGroup grp, int M, Sch
   REQ(0); REQ(1); REQ(2); REQ(3);
   ld_advance();
   REQ(0); REQ(1); REQ(2);
-  if (ld_ok) WAIT_VM(10);
+  if (ld_ok) WAIT_VM(8);
   else WAIT_VM(0);
   BARRIER();
   if (wm == 1) BARRIER();                             // stagger the second wave group by one slot
@@ -184,14 +222,15 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnGroup grp, int M, Sch
   int par = 0;
   while (true) {
     const char* st = smem + par * STAGE;
-    bf16x8 a[2][4], b0[2][2], b1[2][2];
-    // ---------------- phase 0: rows 0..63 x columns 0..31 of the wave tile ----------------
+    bf16x8 a[2][4], b[2][4];
+    // ---------------- phase 0: rows 0..63 of the wave tile ----------------
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[kk][i] = tn_frag(st, kk * 32, wm * 64 + i * 16, lane);
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn) b0[kk][jn] = tn_frag(st + SUB, kk * 32, wn * 32 + jn * 16, lane);
+      for (int jn = 0; jn < 4; ++jn)
+        b[kk][jn] = tn_frag(st + (1 + (jn >> 1)) * SUB, kk * 32, wn * 32 + (jn & 1) * 16, lane);
     }
     REQ(3);
     LOAD_END();
@@ -202,33 +241,16 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnGroup grp, int M, Sch
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b0[kk][jn], acc[i][jn], 0, 0, 0);
+        for (int jn = 0; jn < 4; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][jn], acc[i][jn], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     BARRIER();
-    // ---------------- phase 1: rows 0..63 x columns 32..63 ----------------
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int jn = 0; jn < 2; ++jn) b1[kk][jn] = tn_frag(st + 2 * SUB, kk * 32, wn * 32 + jn * 16, lane);
-    REQ(0);
-    LOAD_END();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-          acc[i][2 + jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b1[kk][jn], acc[i][2 + jn], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    BARRIER();
-    // ---------------- phase 2: rows 64..127 x columns 32..63 ----------------
+    // ---------------- phase 1: rows 64..127 ----------------
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[kk][i] = tn_frag(st + 3 * SUB, kk * 32, wm * 64 + i * 16, lane);
-    REQ(1);
+    REQ(0); REQ(1); REQ(2);
     LOAD_END();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -236,22 +258,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnGroup grp, int M, Sch
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-          acc[4 + i][2 + jn] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b1[kk][jn], acc[4 + i][2 + jn], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    BARRIER();
-    // ---------------- phase 3: rows 64..127 x columns 0..31 ----------------
-    REQ(2);
-    LOAD_END();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-          acc[4 + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b0[kk][jn], acc[4 + i][jn], 0, 0, 0);
+        for (int jn = 0; jn < 4; ++jn)
+          acc[4 + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][jn], acc[4 + i][jn], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     BARRIER();
     par ^= 1;
