@@ -506,10 +506,27 @@ static int tn_pick_splits(int tiles, int M) {
 }
 
 static int launch_tn_group(const TnGroup& g, int M, hipStream_t st) {
-  // long token ranges: the 256x256 persistent form (gemm_tn256.hip); SNX_TN256=0 keeps the 128x128 kernel
+  // long token ranges: the 256x192 persistent form (gemm_tn256.hip); SNX_TN256=0 keeps the 128x128 kernel
   static const int tn256 = getenv("SNX_TN256") ? atoi(getenv("SNX_TN256")) : 1;
   static const int tn256_min_m = getenv("SNX_TN256_MIN_M") ? atoi(getenv("SNX_TN256_MIN_M")) : 8192;
-  if (tn256 && M >= tn256_min_m) return snx_launch_tn256(g, M, st);
+  if (tn256 && M >= tn256_min_m) {
+    // whole 64-row K-steps there; a ragged rest of the token range (< 64 rows) comes back to this kernel
+    const int M64 = M & ~63;
+    const int rc = snx_launch_tn256(g, M64, st);
+    if (rc == SNX_OK) {
+      if (M64 == M) return SNX_OK;
+      TnGroup rest = g;
+      for (int p = 0; p < g.nprob; ++p) {
+        rest.dY[p] = g.dY[p] + (long)M64 * g.N[p];
+        rest.X[p] = g.X[p] + (long)M64 * g.K[p];
+      }
+      const int tiles = g.tile_end[g.nprob - 1];
+      hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles), dim3(256), 2 * 2 * 64 * 256, st, rest, M - M64, tiles, 64);
+      SNX_CHECK_LAUNCH();
+      return SNX_OK;
+    }
+    if (rc != SNX_E_SHAPE) return rc;                 // shapes it does not tile (N % 256, K % 192): fall through
+  }
   const int tiles = g.tile_end[g.nprob - 1];
   int splits = tn_pick_splits(tiles, M);
   int rows = cdiv(M, splits);

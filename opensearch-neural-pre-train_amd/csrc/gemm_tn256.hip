@@ -1,46 +1,45 @@
-// Weight-gradient GEMM, 256x256 persistent "ping-pong" form:  dW[N,K] += dY[M,N]^T * X[M,K]  (contraction over
-// the token rows; replaces the autograd dW = dY^T X of every nn.Linear on the path, the `+=` being
+// Weight-gradient GEMM, 256x256 persistent form:  dW[N,K] += dY[M,N]^T * X[M,K]  (contraction over the token rows;
+// replaces the autograd dW = dY^T X of every nn.Linear on the path, the `+=` being
 // ref:src/train/cli/train_v33_ddp.py:364's gradient accumulation).
 //
 // Why a second form: the 128x128 kernel (gemm.hip) moves 65 FLOP per byte from L2 into LDS -- at 64 B/clk/CU that
 // path saturates together with the matrix pipe (measured with in-kernel stamps, tools/gpu_gemm_trace.py: two waves
-// per SIMD issue MFMAs 60 % of the K loop).  A 256x256 tile halves the bytes and the LDS-DMA instructions per MFMA.
+// per SIMD issue MFMAs 60 % of the K loop).  A 256x256 tile halves the bytes and the LDS-DMA instructions per MFMA,
+// and a 128x128 WAVE tile halves the LDS fragment reads per MFMA again.
 //
-// One 8-wave workgroup per CU (128 KiB LDS), waves 2 (dY column halves) x 4 (X column quarters), wave tile 128 x 64
-// = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16.  The two waves of every SIMD (wave w and w+4) run the same
-// program one barrier apart, so while one multiplies the other reads LDS and issues LDS-DMA:
-//     slot:        s         s+1       s+2       s+3
-//     waves 0-3:   LOAD p    MFMA p    LOAD p+1  MFMA p+1
-//     waves 4-7:   MFMA p-1  LOAD p    MFMA p    LOAD p+1            (every slot ends in one s_barrier)
-// A K-step (64 tokens) is two phases, one 64x64 half of the wave tile each (32 MFMAs = 512 matrix-pipe cycles,
-// long enough to cover the partner's LOAD segment).  Its operands are four 16 KiB sub-tiles (gemm_tn.h image):
-// 0 = dY columns {0-63, 128-191} (the upper 64 rows of both wave rows), 3 = dY columns {64-127, 192-255},
-// 1 / 2 = X columns {64w + 0-31} / {64w + 32-63} of the four wave columns.  Phase 0 reads sub-tiles 0, 1, 2,
-// phase 1 reads 3.  A sub-tile's LDS region is refilled for K-step t+2 in the phase AFTER its last read (two
-// stages of 64 KiB hold t, t+1 and the parts of t+2 already requested): 0, 1, 2 in phase 1 of t, 3 in phase 0 of
-// t+1, 2 DMA instructions per wave each, and every LOAD segment ends with the COUNTED s_waitcnt vmcnt(8): all but
-// the four newest requests have landed.  A request has one K-step to come back from HBM (the operands of a
-// weight gradient are a layer old: nothing of them is in L2).
-//   RAW: a sub-tile is read one barrier after the covering wait of BOTH wave groups.
-//   WAR: a refill is issued one barrier after both groups' reads, and every LOAD segment ends with lgkmcnt(0).
+// One 4-wave workgroup per CU = ONE wave per SIMD with the whole register file: wave tile 128 x 128 = 8 x 8
+// accumulators of v_mfma_f32_16x16x32_bf16 (256 registers) + two sets of 16 fragments (128 registers).  The wave
+// pipelines itself: while the 64 MFMAs of half-step h (32 token rows) run, it reads the fragments of h+1 from LDS
+// (32 ds_read_b64_tr_b16) and requests half-step h+5 from HBM (8 LDS-DMA instructions), all issued into the gaps
+// between MFMAs.  All 160 KiB of LDS form a ring of FIVE half-steps (32 x 256 of dY + 32 x 256 of X = 32 KiB each,
+// stored as 32-row x 128-column sub-tiles in the image of gemm_tn.h).  Per half-step there is ONE barrier:
+//     s_waitcnt vmcnt(24)   -- all but the three newest half-steps requested by this wave have landed, i.e. h+1
+//     s_barrier             -- ... for every wave; and every wave has the fragments of h in registers
+//     request h+5 into the slot of h;  read fragments h+1;  64 MFMAs of h;  s_waitcnt lgkmcnt(0)
+// A request has four half-steps (two 64-token K-steps, 128 KiB in flight per CU) to come back from HBM: the operands
+// of a weight gradient are a layer old, nothing of them is in L2.
 //
-// Work split (no inter-workgroup dependency, float atomics do the reduction as in gemm.hip): XCD x = blockIdx & 7
-// owns the token segment x of 8 and computes ALL output tiles of the group for it, so a token row leaves HBM for
-// one XCD only; its 32 workgroups take tile r*32 + j in round r over the whole segment, in step with each other
-// (the dY / X rows of a K-step are shared through the XCD's L2), and the R < 32 tiles of the last round are cut
-// into floor(32 / R) token pieces each.  Accumulators leave by float atomics at the end of every (tile, piece).
+// Work split (no inter-workgroup dependency; float atomics do the reduction, as in gemm.hip): with n output tiles in
+// the group, P = floor(256 / n) token pieces; workgroup (piece p, tile t) runs ONE long item and flushes its
+// accumulators once.  The 256 - P*n remaining workgroups share the last `tail_len` half-steps of the token range
+// over all tiles, stream-K fashion (contiguous (tile, half-step) ranges), so that every workgroup multiplies about
+// n * steps / 256 half-steps.  Logical workgroup ids are XCD-contiguous (blockIdx & 7 = XCD): an XCD's 32 workgroups
+// are neighbouring tiles of the same token piece and walk it in step, sharing dY / X rows through their L2.
 #include "gemm_tn.h"
 #include "snx.h"
 
 namespace {
 
-constexpr int SUB = 64 * 256;        // one sub-tile: 64 tokens x 128 columns bf16
-constexpr int STAGE = 4 * SUB;       // 64 KiB
-constexpr int NXCD = 8;
+constexpr int HS = 32;               // token rows per half-step
+constexpr int SUB = HS * 256;        // one sub-tile: 32 tokens x 128 columns bf16 = 8 KiB
+constexpr int PART = 2 * SUB;        // one operand slice: 32 tokens x 256 columns
+constexpr int SLOT = 2 * PART;       // dY slice + X slice = 32 KiB
+constexpr int RING = 5;              // 160 KiB
+constexpr int NWG = 256;
+constexpr int TK = 192;              // X columns of an output tile (dY columns: 256)
+constexpr int NJ = 3;                // 32-column accumulator tiles per wave along X (4 along dY): wave tile 128 x 96
 
-__device__ uint4 zero_page256[16];   // 256 B of zeros: DMA source for tokens past M and columns past N / K
-
-struct Item { int tile, sb, se; };   // K-steps [sb, se) of output tile `tile`
+struct Item { int tile, sb, se; };   // K-steps (64 token rows = two half-steps) [sb, se) of output tile `tile`
 
 struct Tile {                        // one output tile of the group
   const bf16_t* dy;                  // dY + n0
@@ -49,27 +48,34 @@ struct Tile {                        // one output tile of the group
   int N, K, n0, k0, inter;
 };
 
-struct Sched { int ntiles, nsteps, seg, W, dbg; };
+struct Sched {
+  int ntiles, nsteps;                // output tiles of the group, K-steps (64 token rows) of the token range
+  int P, nmain, main_len;            // pieces; P * ntiles one-item workgroups over K-steps [0, main_len)
+  int tail_len, tail_u;              // K-steps [main_len, nsteps): tail_u (tile, K-step) units per tail workgroup
+  int dbg;
+};
 
-__device__ __forceinline__ bool item_at(const Sched& s, int it, int x, int j, Item& o) {
-  const int full = s.ntiles / s.W, R = s.ntiles - full * s.W;
-  const int L0 = x * s.seg, L1 = min(s.nsteps, L0 + s.seg);
-  if (L0 >= L1) return false;
-  if (it < full) {
-    o.tile = it * s.W + j; o.sb = L0; o.se = L1;
-    return true;
+// item `it` of logical workgroup L
+__device__ __forceinline__ bool item_at(const Sched& s, int L, int it, Item& o) {
+  if (L < s.nmain) {
+    if (it > 0) return false;
+    const int p = L / s.ntiles;
+    o.tile = L - p * s.ntiles;
+    o.sb = p * s.main_len / s.P;                     // < 2^31: P <= 256, main_len < 2^22 (launcher)
+    o.se = (p + 1) * s.main_len / s.P;
+    return o.sb < o.se;
   }
-  if (it == full && R > 0) {
-    const int p = s.W / R;
-    const int plen = (L1 - L0 + p - 1) / p;
-    const int t = j / p, q = j - t * p;
-    if (t >= R) return false;
-    const int sb = L0 + q * plen, se = min(L1, sb + plen);
-    if (sb >= se) return false;
-    o.tile = full * s.W + t; o.sb = sb; o.se = se;
-    return true;
-  }
-  return false;
+  if (s.tail_len <= 0) return false;
+  const int U = s.ntiles * s.tail_len;
+  const int ub = (L - s.nmain) * s.tail_u, ue = min(U, ub + s.tail_u);
+  if (ub >= ue) return false;
+  const int tile = ub / s.tail_len + it;
+  const int lo = max(ub, tile * s.tail_len), hi = min(ue, (tile + 1) * s.tail_len);
+  if (lo >= hi) return false;
+  o.tile = tile;
+  o.sb = s.main_len + lo - tile * s.tail_len;
+  o.se = s.main_len + hi - tile * s.tail_len;
+  return true;
 }
 
 __device__ __forceinline__ Tile decode(const TnGroup& g, int tile) {
@@ -80,63 +86,45 @@ __device__ __forceinline__ Tile decode(const TnGroup& g, int tile) {
   if (p > 0) tile -= g.tile_end[p - 1];
   Tile t;
   t.N = g.N[p]; t.K = g.K[p]; t.inter = g.inter[p];
-  const int tk = (t.K + 255) >> 8;
+  const int tk = t.K / TK;
   t.n0 = (tile / tk) * 256;
-  t.k0 = (tile % tk) * 256;
+  t.k0 = (tile % tk) * TK;
   t.dy = g.dY[p] + t.n0;
   t.x = g.X[p] + t.k0;
   t.dw = g.dW[p];
   return t;
 }
 
-// Per-lane byte offsets of the two DMA instructions a wave issues per sub-tile: (token row) * ld + column, from the
-// K-step's first token row and the tile's first column.  Sub-tiles 3 / 2 are sub-tiles 0 / 1 shifted by 64 / 32
-// columns (added to the wave-uniform base).  Columns past the matrix edge (K = 1152 -> half a tile) are
-// clamped into it: they only feed accumulators that are never written back.
+// Per-lane byte offsets of a wave's DMA instructions into a 32 x 256 operand slice: (token row) * ld + column from
+// the half-step's first token row and the tile's first column.  Wave w fills rows 8w .. 8w+7 of every sub-tile:
+// instruction k (0, 1) rows 8w + 4k .. +3; sub-tile 1 is sub-tile 0 with the base 128 columns further -- or the
+// SAME base where the tile's second half lies outside the matrix (K = 1152 -> 4.5 tiles): what lands there only
+// feeds accumulators that are never written back.
 struct LaneOff { unsigned a[2], b[2]; };
 
 __device__ __forceinline__ LaneOff lane_offsets(const Tile& t, int wave, int lane) {
   LaneOff o;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (i * 8 + wave) * 4 + (lane >> 4);
-    const int lc = tn_chunk(row, lane & 15) * 8;     // first of the 8 local columns held at this lane's slot
-    int ca = (lc >> 6) * 128 + (lc & 63), cb = (lc >> 5) * 64 + (lc & 31);
-    ca = min(ca, t.N - t.n0 - 72);                   // ca + 64 + 8 <= N - n0
-    cb = min(cb, t.K - t.k0 - 40);
-    o.a[i] = (unsigned)(row * t.N + ca) * 2u;
-    o.b[i] = (unsigned)(row * t.K + cb) * 2u;
+  for (int k = 0; k < 2; ++k) {
+    const int row = wave * 8 + k * 4 + (lane >> 4);
+    const int col = tn_chunk(row, lane & 15) * 8;    // first of the 8 columns held at this lane's slot
+    o.a[k] = (unsigned)(row * t.N + col) * 2u;
+    o.b[k] = (unsigned)(row * t.K + (col < 96 ? col : col - 32)) * 2u;   // X sub-tiles hold 96 columns + 32 of padding
   }
   return o;
 }
 
-// request sub-tile C of the K-step starting at token tok0 into `stage` (tok0 + 64 <= M)
-template <int C>
-__device__ __forceinline__ void dma_sub(const Tile& t, const LaneOff& o, int tok0, char* stage, int wave) {
-  constexpr bool isA = (C == 0 || C == 3);
-  // (the instruction's immediate offset would move the LDS address too: the column shift goes into the base)
-  const char* base = isA ? (const char*)(t.dy + (long)tok0 * t.N + (C == 3 ? 64 : 0))
-                         : (const char*)(t.x + (long)tok0 * t.K + (C == 2 ? 32 : 0));
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const char* src = base + (isA ? o.a[i] : o.b[i]);
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + C * SUB + (i * 8 + wave) * 1024), 16, 0, 0);
-  }
-}
-
-// the K-step that holds the last, partly filled 64 token rows of the matrix: rows past M read zeros
-template <int C>
-__device__ __forceinline__ void dma_sub_tail(const Tile& t, const LaneOff& o, int tok0, int M, char* stage, int wave,
-                                             int lane) {
-  constexpr bool isA = (C == 0 || C == 3);
-  const char* base = isA ? (const char*)(t.dy + (long)tok0 * t.N) : (const char*)(t.x + (long)tok0 * t.K);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (i * 8 + wave) * 4 + (lane >> 4);
-    const char* src = tok0 + row < M ? base + (isA ? o.a[i] : o.b[i]) + (C == 3 ? 128 : C == 2 ? 64 : 0)
-                                     : (const char*)zero_page256 + (lane & 15) * 16;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + C * SUB + (i * 8 + wave) * 1024), 16, 0, 0);
-  }
+// DMA instruction pair k (0..3) of the half-step starting at token tok0 into `slot`: rows 8w + 4(k >> 1) .. +3 of
+// sub-tile (k & 1) of the dY slice and of the X slice.  8 DMA instructions per wave and half-step, no branches.  The
+// launcher hands this kernel whole K-steps only (M % 64 == 0; the ragged rest goes to the 128x128 kernel).
+__device__ __forceinline__ void request_pair(const Tile& t, const LaneOff& o, int tok0, char* slot, int wave, int k) {
+  const int a2 = ((k & 1) && t.n0 + 128 < t.N) ? 256 : 0, b2 = (k & 1) ? 192 : 0;
+  const char* ba = (const char*)(t.dy + (long)tok0 * t.N) + a2;
+  const char* bb = (const char*)(t.x + (long)tok0 * t.K) + b2;
+  char* d = slot + (wave * 8 + (k >> 1) * 4) * 256 + (k & 1) * SUB;
+  // (default cache policy: nt loads measured no faster here, 489 vs 482 us per layer group)
+  __builtin_amdgcn_global_load_lds(GLB_PTR(ba + o.a[k >> 1]), LDS_PTR(d), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(GLB_PTR(bb + o.b[k >> 1]), LDS_PTR(d + PART), 16, 0, 0);
 }
 
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -148,173 +136,230 @@ __device__ __forceinline__ void dma_sub_tail(const Tile& t, const LaneOff& o, in
     __builtin_amdgcn_sched_barrier(0);     \
   } while (0)
 
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+struct Frags { bf16x8 a[8], b[2 * NJ]; };   // [32-wide tile][16-token half] -> index 2 * tile + half
+
+// tn_frag (gemm_tn.h) with the two transposing reads as volatile asm: hipcc's waitcnt pass puts s_waitcnt vmcnt(0)
+// in front of every LDS read it can see while LDS-DMA writes are in flight (it cannot tell the ring slots apart),
+// which would drain the whole request pipeline once per half-step.  The results are first used behind the
+// s_waitcnt lgkmcnt(0) that ends the half-step.
+// Operand fragment of v_mfma_f32_32x32x16_bf16: lane l holds, for MFMA row / column (l & 31) of the 32-wide tile at
+// column `cbase` of the sub-tile, the 8 contraction elements (token rows) mb + 8 (l >> 5) .. + 7.
+__device__ __forceinline__ bf16x8 tn_frag_opaque(const char* tile, int mb, int cbase, int lane) {
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  const int ch = ((cbase + (lane & 16)) >> 3) + (tp >> 1);
+  const int r0 = mb + 8 * (lane >> 5) + tq, r1 = r0 + 4;
+  const unsigned a0 = (unsigned)(uintptr_t)LDS_PTR(tile + r0 * 256 + tn_chunk(r0, ch) * 16 + (tp & 1) * 8);
+  const unsigned a1 = (unsigned)(uintptr_t)LDS_PTR(tile + r1 * 256 + tn_chunk(r1, ch) * 16 + (tp & 1) * 8);
+  bf16x4 v0, v1;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v0) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v1) : "v"(a1));
+  return (bf16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+}
+
+// fragment q of the half-step in `slot`: q = 0..7 dY (32-row tile q >> 1, token rows 16 (q & 1) ..), q = 8..8+2*NJ-1 X
+__device__ __forceinline__ void read_frag(Frags& f, int q, const char* slot, int wm, int wn, int lane) {
+  if (q < 8) f.a[q] = tn_frag_opaque(slot + wm * SUB, (q & 1) * 16, (q >> 1) * 32, lane);
+  else f.b[q - 8] = tn_frag_opaque(slot + PART + wn * SUB, (q & 1) * 16, ((q - 8) >> 1) * 32, lane);
+}
+
+// The accumulators are pinned to AGPRs through the asm constraint (left to itself hipcc moves them to VGPRs and
+// scratch as soon as the flush reads them), and a volatile asm is a barrier for memory instructions: the LDS reads
+// and DMA requests written between two of these stay there -- the interleaving in the K loop is the source order.
+__device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// first half-step of a (tile, token piece): C = 0, so the accumulators are never written by anything but an MFMA
+__device__ __forceinline__ void mfma_pinned_first(f32x16& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
+
 }  // namespace
 
-__global__ __launch_bounds__(512) void gemm_tn256_kernel(TnGroup grp, int M, Sched sch) {
+#ifdef SNX_GEMM_TRACE
+// diagnostics build (-DSNX_GEMM_TRACE): per workgroup shader-clock and constant-clock (100 MHz) ticks around the K
+// loop and the number of K-steps, for the in-kernel clock and the cycles per half-step (tools/gpu_tnbench.py)
+__device__ unsigned long long* g_tn256_trace = nullptr;
+extern "C" int snx_tn256_trace_set(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tn256_trace), &buf, sizeof(buf));
+}
+#endif
+
+template <bool NODMA>
+__global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sched sch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int li = lane & 15, g = lane >> 4;
-  const int xcd = blockIdx.x & (NXCD - 1), jw = blockIdx.x >> 3;
-  const int nitems = sch.ntiles / sch.W + ((sch.ntiles % sch.W) ? 1 : 0);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int L = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous logical id
 
-  auto next_item = [&](int from, Item& o) {          // first non-empty item with index >= from, or -1
-    for (int it = from; it < nitems; ++it)
-      if (item_at(sch, it, xcd, jw, o)) return it;
-    return -1;
-  };
-
-  // ---- the two streams: requests (ld_*) run 7 sub-tiles ahead of the reads (cp_*) ----
-  Item ld_item, cp_item;
-  int ld_it = next_item(0, ld_item);
-  if (ld_it < 0) return;
-  int cp_it = ld_it;
+  // ---- two streams over the same item sequence (items count K-steps of 64 tokens = two half-steps): requests
+  //      (ld_*) run RING half-steps ahead of the MFMAs (cp_*) ----
+  // (item_at divides: it runs once per item, never inside the K loop)
+  Item ld_item, cp_item, ld_next, cp_next;
+  if (!item_at(sch, L, 0, ld_item)) return;
+  int ld_it = 0, cp_it = 0;
   cp_item = ld_item;
+  bool ld_has_next = item_at(sch, L, 1, ld_next), cp_has_next = ld_has_next;
+  cp_next = ld_next;
   Tile ld_tile = decode(grp, ld_item.tile), cp_tile = ld_tile;
   LaneOff ld_off = lane_offsets(ld_tile, wave, lane);
   int ld_s = ld_item.sb, cp_s = cp_item.sb;
-  int ld_par = 0;
-  bool ld_ok = true;
-  auto ld_advance = [&]() {                           // the request stream moves on to its next K-step
-    ld_par ^= 1;
-    if (++ld_s == ld_item.se) {
-      ld_it = next_item(ld_it + 1, ld_item);
-      ld_ok = ld_it >= 0;
-      if (ld_ok) {
-        ld_tile = decode(grp, ld_item.tile);
-        ld_off = lane_offsets(ld_tile, wave, lane);
-        ld_s = ld_item.sb;
-      }
+  int ld_slot = 0;
+  // DMA instruction pair k (0..3) of one half-step of the request stream: sub-tile (k & 1) of dY and of X ... see
+  // request_pair; after the fourth pair the stream's slot moves on
+  auto issue = [&](int half, int k) {
+    if (!NODMA)
+      request_pair(ld_tile, ld_off, (sch.dbg & 4) ? 0 : ld_s * 64 + half * HS, smem + ld_slot * SLOT, wave, k);
+    if (k == 3) ld_slot = ld_slot + 1 == RING ? 0 : ld_slot + 1;
+  };
+  auto issue_all = [&](int half) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) issue(half, k);
+  };
+  // ... and the stream moves on to its next K-step.  At its end it PARKS on its last K-step: the K loop keeps
+  // requesting (no branch in its body); a request always goes into the ring slot whose fragments are already in
+  // registers, so re-requesting old rows there is harmless.
+  auto ld_advance = [&]() {
+    if (ld_s + 1 < ld_item.se) {
+      ++ld_s;
+    } else if (ld_has_next) {
+      ld_item = ld_next;
+      ld_has_next = item_at(sch, L, ++ld_it + 1, ld_next);
+      ld_tile = decode(grp, ld_item.tile);
+      ld_off = lane_offsets(ld_tile, wave, lane);
+      ld_s = ld_item.sb;
     }
   };
-#define REQ(C)                                                                                          \
-  do {                                                                                                  \
-    if (ld_ok && !(sch.dbg & 2)) {                                                                      \
-      const int tok0 = (sch.dbg & 4) ? 0 : ld_s * 64;                                                   \
-      if (tok0 + 64 <= M) dma_sub<C>(ld_tile, ld_off, tok0, smem + ld_par * STAGE, wave);               \
-      else dma_sub_tail<C>(ld_tile, ld_off, tok0, M, smem + ld_par * STAGE, wave, lane);                \
-    }                                                                                                   \
-  } while (0)
-#define LOAD_END()                       \
-  do {                                   \
-    if (ld_ok) WAIT_VM(8);               \
-    else WAIT_VM(0);                     \
-    WAIT_LGKM0();                        \
-    BARRIER();                           \
-  } while (0)
 
-  // prologue: sub-tiles 0..3 of the first K-step, 0..2 of the second
-  REQ(0); REQ(1); REQ(2); REQ(3);
+  f32x16 acc[4][NJ];
+
+  // prologue: half-steps 0..4 requested (K-steps 0, 1 and the first half of 2); fragments of half-step 0 in registers
+  issue_all(0); issue_all(1);
   ld_advance();
-  REQ(0); REQ(1); REQ(2);
-  if (ld_ok) WAIT_VM(8);
-  else WAIT_VM(0);
+  issue_all(0); issue_all(1);
+  ld_advance();
+  issue_all(0);
+  asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
   BARRIER();
-  if (wm == 1) BARRIER();                             // stagger the second wave group by one slot
+  Frags f0, f1;
+#pragma unroll
+  for (int q = 0; q < 8 + 2 * NJ; ++q) read_frag(f0, q, smem, wm, wn, lane);
+  WAIT_LGKM0();
+  int rd_slot = 1;                                    // slot of the half-step whose fragments are read next
 
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int jn = 0; jn < 4; ++jn) acc[i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto next_rd = [&]() { rd_slot = rd_slot + 1 == RING ? 0 : rd_slot + 1; };
+  // One half-step: 8 * NJ MFMAs (32x32x16: 4 x NJ tiles, two 16-token halves) on `cur`; between them (source order =
+  // issue order, see mfma_pinned) the 8 DMA instructions of the request stream behind MFMAs 0..3 and the 8 + 2 NJ
+  // fragments of the next half-step (2 ds_read_b64_tr_b16 each) behind MFMAs 4...  A 32x32x16 MFMA occupies the
+  // matrix pipe for 32 cycles and the wave's issue for 8: 24 cycles per gap for other instructions (with 16x16x32
+  // MFMAs, 8 cycles per gap, a half-step took 1312 instead of 768 cycles).  The body has NO branch (one s_cbranch
+  // per gap cost the single wave of a SIMD 64 cycles per MFMA instead of 32): requests and reads are unconditional
+  // -- past the end of the streams they re-request parked rows and read fragments nobody uses.
+#define HALF_STEP(cur, nxt, half, FIRST)                                                        \
+  do {                                                                                          \
+    WAIT_VM(24);                                                                                \
+    BARRIER();                                                                                  \
+    const char* rs = smem + rd_slot * SLOT;                                                     \
+    _Pragma("unroll") for (int m = 0; m < 8 * NJ; ++m) {                                        \
+      const int h = m / (4 * NJ), i = (m / NJ) & 3, j = m % NJ;   /* token half, dY tile, X tile */ \
+      if (FIRST && h == 0) mfma_pinned_first(acc[i][j], cur.a[2 * i], cur.b[2 * j]);            \
+      else mfma_pinned(acc[i][j], cur.a[2 * i + h], cur.b[2 * j + h]);                          \
+      if (m < 4) issue(half, m);                                                                \
+      if (m >= 4 && m < 4 + 8 + 2 * NJ) read_frag(nxt, m - 4, rs, wm, wn, lane);                \
+    }                                                                                           \
+    WAIT_LGKM0();                                                                               \
+    next_rd();                                                                                  \
+  } while (0)
 
-  int par = 0;
-  while (true) {
-    const char* st = smem + par * STAGE;
-    bf16x8 a[2][4], b[2][4];
-    // ---------------- phase 0: rows 0..63 of the wave tile ----------------
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[kk][i] = tn_frag(st, kk * 32, wm * 64 + i * 16, lane);
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn)
-        b[kk][jn] = tn_frag(st + (1 + (jn >> 1)) * SUB, kk * 32, wn * 32 + (jn & 1) * 16, lane);
-    }
-    REQ(3);
-    LOAD_END();
+#ifdef SNX_GEMM_TRACE
+  const unsigned long long tr_c0 = __builtin_amdgcn_s_memtime(), tr_r0 = __builtin_amdgcn_s_memrealtime();
+  int tr_steps = 0;
+#endif
+  bool first = true;                                  // first K-step of a (tile, token piece)
+  while (true) {                                      // one K-step of the MFMA stream per iteration
+#ifdef SNX_GEMM_TRACE
+    ++tr_steps;
+#endif
+    // the request stream stands at the second half of a K-step
+    if (first) HALF_STEP(f0, f1, 1, true);
+    else HALF_STEP(f0, f1, 1, false);
+    first = false;
     ld_advance();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][jn], acc[i][jn], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    BARRIER();
-    // ---------------- phase 1: rows 64..127 ----------------
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[kk][i] = tn_frag(st + 3 * SUB, kk * 32, wm * 64 + i * 16, lane);
-    REQ(0); REQ(1); REQ(2);
-    LOAD_END();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
-          acc[4 + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][jn], acc[4 + i][jn], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    BARRIER();
-    par ^= 1;
-
+    HALF_STEP(f1, f0, 0, false);
+    // ---- end of a K-step; at the end of a (tile, token piece) the accumulators are added to the gradient
+    //   acc[i][j][v] = dW[n0 + 128 wm + 32 i + 8 (v >> 2) + 4 (lane >> 5) + (v & 3)][k0 + 96 wn + 32 j + (lane & 31)]
     if (++cp_s == cp_item.se) {
-      // ---- end of a (tile, token piece): add the accumulators to the gradient ----
-      // acc[i][jn][r] = dW[n0 + wm*128 + i*16 + 4g + r][k0 + wn*64 + jn*16 + li]
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // MFMA results -> VALU reads: the asm MFMAs are opaque to the hazard pass
+      if (!(sch.dbg & 1)) {                           // tiles are whole: N % 256 == 0, K % 192 == 0 (launcher)
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int n = cp_tile.n0 + wm * 128 + i * 16 + g * 4 + r;
-          const bool nok = n < cp_tile.N;
-          if (cp_tile.inter > 0)                      // dY columns are in the interleaved GeGLU order
-            n = ((n & 63) < 32) ? 32 * (n >> 6) + (n & 31) : cp_tile.inter + 32 * (n >> 6) + (n & 31);
+          for (int v = 0; v < 16; ++v) {
+            int n = cp_tile.n0 + wm * 128 + i * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+            if (cp_tile.inter > 0)                    // dY columns are in the interleaved GeGLU order
+              n = ((n & 63) < 32) ? 32 * (n >> 6) + (n & 31) : cp_tile.inter + 32 * (n >> 6) + (n & 31);
+            float* row = cp_tile.dw + (long)n * cp_tile.K + cp_tile.k0 + wn * 96 + (lane & 31);
 #pragma unroll
-          for (int jn = 0; jn < 4; ++jn) {
-            const int k = cp_tile.k0 + wn * 64 + jn * 16 + li;
-            if (nok && k < cp_tile.K && !(sch.dbg & 1)) atomicAdd(cp_tile.dw + (long)n * cp_tile.K + k, acc[i][jn][r]);
-            acc[i][jn][r] = 0.f;
+            for (int j = 0; j < NJ; ++j) atomicAdd(row + j * 32, acc[i][j][v]);
           }
-        }
-      cp_it = next_item(cp_it + 1, cp_item);
-      if (cp_it < 0) break;
+      }
+      if (!cp_has_next) break;
+      first = true;
+      cp_item = cp_next;
+      cp_has_next = item_at(sch, L, ++cp_it + 1, cp_next);
       cp_tile = decode(grp, cp_item.tile);
       cp_s = cp_item.sb;
     }
   }
-  if (wm == 0) BARRIER();                             // balance the stagger barrier
-#undef REQ
-#undef LOAD_END
+#undef HALF_STEP
+#ifdef SNX_GEMM_TRACE
+  if (threadIdx.x == 0 && g_tn256_trace) {
+    unsigned long long* o = g_tn256_trace + 4l * blockIdx.x;
+    o[0] = __builtin_amdgcn_s_memtime() - tr_c0;
+    o[1] = __builtin_amdgcn_s_memrealtime() - tr_r0;
+    o[2] = tr_steps;
+    o[3] = L;
+  }
+#endif
 }
 
 int snx_launch_tn256(const TnGroup& g128, int M, hipStream_t st) {
   TnGroup g = g128;
   int run = 0;
   for (int p = 0; p < g.nprob; ++p) {
-    run += cdiv(g.N[p], 256) * cdiv(g.K[p], 256);
+    if ((g.N[p] % 256) || (g.K[p] % TK)) return SNX_E_SHAPE;
+    run += (g.N[p] / 256) * (g.K[p] / TK);
     g.tile_end[p] = run;
   }
+  if (run > NWG) return SNX_E_SHAPE;                  // caller falls back to the 128x128 kernel
   Sched s;
   s.ntiles = run;
-  s.nsteps = cdiv(M, 64);
-  s.seg = cdiv(s.nsteps, NXCD);
-  s.W = 32;
-  static const int dbg = getenv("SNX_TN256_DBG") ? atoi(getenv("SNX_TN256_DBG")) : 0;   // diagnostics: 1 = no atomics, 2 = no DMA
+  s.nsteps = cdiv(M, 2 * HS);
+  s.P = NWG / run;
+  s.nmain = s.P * run;
+  const int wt = NWG - s.nmain;
+  // every workgroup should multiply about ntiles * nsteps / 256 half-steps; the tail workgroups flush once per tile
+  // they touch, which SNX_TN256_TAIL_PCT (default 95) takes off their share
+  static const int tail_pct = getenv("SNX_TN256_TAIL_PCT") ? atoi(getenv("SNX_TN256_TAIL_PCT")) : 95;
+  s.tail_len = wt > 0 ? (int)((long)s.nsteps * wt * tail_pct / (100L * NWG)) : 0;
+  s.main_len = s.nsteps - s.tail_len;
+  s.tail_u = wt > 0 ? cdiv((long)s.ntiles * s.tail_len, wt) : 0;
+  // diagnostics: 1 = no atomics, 2 = no DMA, 4 = L2-resident operands
+  static const int dbg = getenv("SNX_TN256_DBG") ? atoi(getenv("SNX_TN256_DBG")) : 0;
   s.dbg = dbg;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * STAGE);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RING * SLOT);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              RING * SLOT);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(NXCD * s.W), dim3(512), 2 * STAGE, st, g, M, s);
+  if (dbg & 2) hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(NWG), dim3(256), RING * SLOT, st, g, M, s);
+  else hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(NWG), dim3(256), RING * SLOT, st, g, M, s);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }

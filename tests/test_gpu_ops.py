@@ -323,42 +323,45 @@ def test_gemm_tn_group_equals_separate_launches(dev):
 
 @pytest.mark.parametrize("M", [8192, 8263, 20000])
 def test_gemm_tn_256_form(dev, M):
-    """Token ranges of 8192 rows and more run the 256x256 persistent kernel (gemm_tn256.hip): XCD token segments
-    (the last one shorter / ragged), whole rounds plus a remainder round cut into token pieces, a column tile half
-    outside the matrix (K = 1152 -> 4.5 tiles; N = 384 -> 1.5), the interleaved GeGLU row order, alone and grouped.
-    Reference: fp32 matmul of the same bf16 operands."""
+    """Token ranges of 8192 rows and more run the 256x192 persistent kernel (gemm_tn256.hip) when N % 256 == 0 and
+    K % 192 == 0: one long item per (token piece, tile) workgroup plus the stream-K tail workgroups, a ragged rest
+    of the token range (M % 64 rows, handed to the 128x128 kernel), the interleaved GeGLU row order, alone and
+    grouped; a group with a shape the form does not tile falls back as a whole.  Reference: fp32 matmul of the same
+    bf16 operands."""
     ops = _ops()
-    H, I = 256, 384
     g = torch.Generator().manual_seed(M)
     mk = lambda r, c, s=0.1: (torch.randn(r, c, generator=g) * s).to(dev).to(BF16)   # noqa: E731
-    shapes = [(3 * H, H, False), (2 * I, H, True), (H, 3 * I, False), (I, H, False)]
-    probs, refs = [], []
-    for N, K, inter in shapes:
-        dy, x = mk(M, N), mk(M, K, 1.0)
-        dw = torch.randn(N, K, generator=g).to(dev)
-        dyn = dy.float()
-        if inter:                     # interleaved columns [a(32) g(32)]* -> natural [a | g]
-            dyn = torch.cat([dyn.view(M, N // 64, 2, 32)[:, :, 0].reshape(M, -1),
-                             dyn.view(M, N // 64, 2, 32)[:, :, 1].reshape(M, -1)], 1)
-        refs.append(dw + dyn.t() @ x.float())
-        probs.append((dy, x, dw, inter))
-    singles = [(dy, x, dw.clone(), inter) for dy, x, dw, inter in probs]
-    ops.gemm_tn_accum_group(probs)
-    for (dy, x, dw, inter), ref in zip(probs, refs):
-        err = (dw - ref).abs().max().item()
-        assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
-    for (dy, x, dw, inter), ref in zip(singles, refs):
-        (ops.gemm_tn_accum_interleaved if inter else ops.gemm_tn_accum)(dy, x, dw)
-        err = (dw - ref).abs().max().item()
-        assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
+    for shapes in ([(768, 384, False), (768, 384, True), (256, 1152, False), (512, 384, False)],
+                   [(768, 384, False), (384, 256, False)]):
+        probs, refs = [], []
+        for N, K, inter in shapes:
+            dy, x = mk(M, N), mk(M, K, 1.0)
+            dw = torch.randn(N, K, generator=g).to(dev)
+            dyn = dy.float()
+            if inter:                     # interleaved columns [a(32) g(32)]* -> natural [a | g]
+                dyn = torch.cat([dyn.view(M, N // 64, 2, 32)[:, :, 0].reshape(M, -1),
+                                 dyn.view(M, N // 64, 2, 32)[:, :, 1].reshape(M, -1)], 1)
+            refs.append(dw + dyn.t() @ x.float())
+            probs.append((dy, x, dw, inter))
+        singles = [(dy, x, dw.clone(), inter) for dy, x, dw, inter in probs]
+        ops.gemm_tn_accum_group(probs)
+        for (dy, x, dw, inter), ref in zip(probs, refs):
+            err = (dw - ref).abs().max().item()
+            assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
+        for (dy, x, dw, inter), ref in zip(singles, refs):
+            (ops.gemm_tn_accum_interleaved if inter else ops.gemm_tn_accum)(dy, x, dw)
+            err = (dw - ref).abs().max().item()
+            assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
 
 
-def test_gemm_tn_256_layout(dev):
-    """Exact check of the 256x256 form: dY = a 0/1 selection pattern, so dW[n, :] = X[row(n), :] bit for bit
-    (catches n/k swaps, sub-tile column maps and token-segment seams)."""
+@pytest.mark.parametrize("M", [8192 + 64, 8192 + 37])
+def test_gemm_tn_256_layout(dev, M):
+    """Exact check of the 256x192 form: dY = a 0/1 selection pattern, so dW[n, :] = X[row(n), :] bit for bit
+    (catches n/k swaps, sub-tile column maps, token-piece seams and the ragged rest)."""
     ops = _ops()
-    M, N, K = 8192 + 64, 512, 640
+    N, K = 512, 768
     perm = (torch.arange(N, device=dev) * 37 + 5) % M
+    perm[-1] = M - 1
     dy = torch.zeros(M, N, device=dev)
     dy[perm, torch.arange(N, device=dev)] = 1.0
     x = ((torch.arange(M * K, device=dev, dtype=torch.float32).reshape(M, K) % 199) - 99.0).to(BF16)
