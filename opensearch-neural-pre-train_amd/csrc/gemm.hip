@@ -506,7 +506,7 @@ static int tn_pick_splits(int tiles, int M) {
 }
 
 static int launch_tn_group(const TnGroup& g, int M, hipStream_t st) {
-  // long token ranges: the 256x192 persistent form (gemm_tn256.hip); SNX_TN256=0 keeps the 128x128 kernel
+  // long token ranges: the 256x256 persistent form (gemm_tn256.hip); SNX_TN256=0 keeps the 128x128 kernel
   static const int tn256 = getenv("SNX_TN256") ? atoi(getenv("SNX_TN256")) : 1;
   static const int tn256_min_m = getenv("SNX_TN256_MIN_M") ? atoi(getenv("SNX_TN256_MIN_M")) : 8192;
   if (tn256 && M >= tn256_min_m) {
@@ -525,7 +525,7 @@ static int launch_tn_group(const TnGroup& g, int M, hipStream_t st) {
       SNX_CHECK_LAUNCH();
       return SNX_OK;
     }
-    if (rc != SNX_E_SHAPE) return rc;                 // shapes it does not tile (N % 256, K % 192): fall through
+    if (rc != SNX_E_SHAPE) return rc;                 // groups it does not take (> 256 tiles): fall through
   }
   const int tiles = g.tile_end[g.nprob - 1];
   int splits = tn_pick_splits(tiles, M);

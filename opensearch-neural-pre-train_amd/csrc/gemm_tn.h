@@ -35,5 +35,6 @@ struct TnGroup {
 };
 
 
-// 256x256 persistent form (gemm_tn256.hip); returns SNX_OK or a HIP error code
+// 256x256 persistent form (gemm_tn256.hip): SNX_OK, SNX_E_SHAPE when it does not take the group (more than 256
+// tiles), or a HIP error code.  M % 64 == 0.
 int snx_launch_tn256(const TnGroup& g, int M, hipStream_t st);

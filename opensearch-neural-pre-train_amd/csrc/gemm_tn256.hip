@@ -4,27 +4,44 @@
 //
 // Why a second form: the 128x128 kernel (gemm.hip) moves 65 FLOP per byte from L2 into LDS -- at 64 B/clk/CU that
 // path saturates together with the matrix pipe (measured with in-kernel stamps, tools/gpu_gemm_trace.py: two waves
-// per SIMD issue MFMAs 60 % of the K loop).  A 256x256 tile halves the bytes and the LDS-DMA instructions per MFMA,
-// and a 128x128 WAVE tile halves the LDS fragment reads per MFMA again.
+// per SIMD issue MFMAs 60 % of the K loop) -- and its operands are cold (a layer old).  A 256x256 tile moves 131
+// FLOP per byte, and a 128x128 WAVE tile halves the LDS fragment reads per MFMA.
 //
-// One 4-wave workgroup per CU = ONE wave per SIMD with the whole register file: wave tile 128 x 128 = 8 x 8
-// accumulators of v_mfma_f32_16x16x32_bf16 (256 registers) + two sets of 16 fragments (128 registers).  The wave
-// pipelines itself: while the 64 MFMAs of half-step h (32 token rows) run, it reads the fragments of h+1 from LDS
-// (32 ds_read_b64_tr_b16) and requests half-step h+5 from HBM (8 LDS-DMA instructions), all issued into the gaps
-// between MFMAs.  All 160 KiB of LDS form a ring of FIVE half-steps (32 x 256 of dY + 32 x 256 of X = 32 KiB each,
+// One 4-wave workgroup per CU = ONE wave per SIMD with the whole register file: wave tile 128 x 128 = 4 x 4
+// accumulator tiles of v_mfma_f32_32x32x16_bf16 (all 256 AGPRs) + two sets of 16 fragments (128 VGPRs).  The wave
+// pipelines itself: while the 32 MFMAs of half-step h (32 token rows) run, it requests half-step h+5 from HBM
+// (8 LDS-DMA instructions) and reads the fragments of h+1 from LDS (32 ds_read_b64_tr_b16), all issued into the
+// gaps between MFMAs.  All 160 KiB of LDS form a ring of FIVE half-steps (32 x 256 of dY + 32 x 256 of X = 32 KiB,
 // stored as 32-row x 128-column sub-tiles in the image of gemm_tn.h).  Per half-step there is ONE barrier:
 //     s_waitcnt vmcnt(24)   -- all but the three newest half-steps requested by this wave have landed, i.e. h+1
 //     s_barrier             -- ... for every wave; and every wave has the fragments of h in registers
-//     request h+5 into the slot of h;  read fragments h+1;  64 MFMAs of h;  s_waitcnt lgkmcnt(0)
-// A request has four half-steps (two 64-token K-steps, 128 KiB in flight per CU) to come back from HBM: the operands
-// of a weight gradient are a layer old, nothing of them is in L2.
+//     request h+5 into the slot of h;  read fragments h+1;  32 MFMAs of h;  s_waitcnt lgkmcnt(0)
+// A request has four half-steps (two 64-token K-steps, 128 KiB in flight per CU) to come back from HBM.
+//
+// What the compiler needed (each measured): the accumulators pinned to AGPRs by an asm constraint and written by
+// MFMAs only (C = 0 form on the first half-step of an item; otherwise they move to VGPRs and scratch once the flush
+// reads them); the LDS reads as volatile asm (otherwise s_waitcnt vmcnt(0) in front of each while LDS-DMA is in
+// flight); 32x32x16, not 16x16x32 MFMAs (24 instead of 8 free issue cycles per MFMA for the 70-odd other
+// instructions of a half-step); NO branch in the K loop body (one s_cbranch per MFMA gap: 64 instead of 32 cycles
+// per MFMA) -- past the end of a stream requests re-fetch parked rows and reads fetch fragments nobody uses -- and
+// no division in it (the item schedule is advanced once per item); three copies of the body at most (a fourth and
+// the register allocator spills).
 //
 // Work split (no inter-workgroup dependency; float atomics do the reduction, as in gemm.hip): with n output tiles in
 // the group, P = floor(256 / n) token pieces; workgroup (piece p, tile t) runs ONE long item and flushes its
-// accumulators once.  The 256 - P*n remaining workgroups share the last `tail_len` half-steps of the token range
-// over all tiles, stream-K fashion (contiguous (tile, half-step) ranges), so that every workgroup multiplies about
-// n * steps / 256 half-steps.  Logical workgroup ids are XCD-contiguous (blockIdx & 7 = XCD): an XCD's 32 workgroups
+// accumulators once (an XCD-segment split tried first flushed three times per workgroup: 188 MB of atomics and
+// 90 us per launch).  The 256 - P*n remaining workgroups share the last `tail_len` K-steps of the token range over
+// all tiles, stream-K fashion (contiguous (tile, K-step) ranges), so that every workgroup multiplies about
+// n * steps / 256 K-steps.  Logical workgroup ids are XCD-contiguous (blockIdx & 7 = XCD): an XCD's 32 workgroups
 // are neighbouring tiles of the same token piece and walk it in step, sharing dY / X rows through their L2.
+// N and K need only be multiples of 128 (a tile may lie half outside the matrix: its DMA re-reads valid columns
+// and its flush is predicated); M a multiple of 64 (the launcher hands a ragged rest to the 128x128 kernel).
+//
+// Measured (layer group of the 149 M model, 36,864 tokens, 369 GFLOP): 356 us in the training step = 1.0 PFLOP/s
+// (128x128 kernel: 479 us); back to back in a microbenchmark 455 us at an in-kernel clock of 1.65 GHz (the chip
+// lowers its clock under the sustained load), compute-only 300 us.  In-kernel stamps: tools/gpu_tnbench.py with a
+// -DSNX_GEMM_TRACE build.  Forms tried before this one (8-wave ping-pong with quadrant / half phases, 16x16x32 MFMAs):
+// 585 / 477 / 521 us in the same microbenchmark; 256x192 tiles with 192 accumulators: 482 us.
 #include "gemm_tn.h"
 #include "snx.h"
 
@@ -36,8 +53,8 @@ constexpr int PART = 2 * SUB;        // one operand slice: 32 tokens x 256 colum
 constexpr int SLOT = 2 * PART;       // dY slice + X slice = 32 KiB
 constexpr int RING = 5;              // 160 KiB
 constexpr int NWG = 256;
-constexpr int TK = 192;              // X columns of an output tile (dY columns: 256)
-constexpr int NJ = 3;                // 32-column accumulator tiles per wave along X (4 along dY): wave tile 128 x 96
+constexpr int TK = 256;              // X columns of an output tile (dY columns: 256)
+constexpr int NJ = 4;                // 32-column accumulator tiles per wave along X (4 along dY): wave tile 128 x 128
 
 struct Item { int tile, sb, se; };   // K-steps (64 token rows = two half-steps) [sb, se) of output tile `tile`
 
@@ -86,7 +103,7 @@ __device__ __forceinline__ Tile decode(const TnGroup& g, int tile) {
   if (p > 0) tile -= g.tile_end[p - 1];
   Tile t;
   t.N = g.N[p]; t.K = g.K[p]; t.inter = g.inter[p];
-  const int tk = t.K / TK;
+  const int tk = (t.K + TK - 1) / TK;
   t.n0 = (tile / tk) * 256;
   t.k0 = (tile % tk) * TK;
   t.dy = g.dY[p] + t.n0;
@@ -109,7 +126,7 @@ __device__ __forceinline__ LaneOff lane_offsets(const Tile& t, int wave, int lan
     const int row = wave * 8 + k * 4 + (lane >> 4);
     const int col = tn_chunk(row, lane & 15) * 8;    // first of the 8 columns held at this lane's slot
     o.a[k] = (unsigned)(row * t.N + col) * 2u;
-    o.b[k] = (unsigned)(row * t.K + (col < 96 ? col : col - 32)) * 2u;   // X sub-tiles hold 96 columns + 32 of padding
+    o.b[k] = (unsigned)(row * t.K + col) * 2u;
   }
   return o;
 }
@@ -118,7 +135,7 @@ __device__ __forceinline__ LaneOff lane_offsets(const Tile& t, int wave, int lan
 // sub-tile (k & 1) of the dY slice and of the X slice.  8 DMA instructions per wave and half-step, no branches.  The
 // launcher hands this kernel whole K-steps only (M % 64 == 0; the ragged rest goes to the 128x128 kernel).
 __device__ __forceinline__ void request_pair(const Tile& t, const LaneOff& o, int tok0, char* slot, int wave, int k) {
-  const int a2 = ((k & 1) && t.n0 + 128 < t.N) ? 256 : 0, b2 = (k & 1) ? 192 : 0;
+  const int a2 = ((k & 1) && t.n0 + 128 < t.N) ? 256 : 0, b2 = ((k & 1) && t.k0 + 128 < t.K) ? 256 : 0;
   const char* ba = (const char*)(t.dy + (long)tok0 * t.N) + a2;
   const char* bb = (const char*)(t.x + (long)tok0 * t.K) + b2;
   char* d = slot + (wave * 8 + (k >> 1) * 4) * 256 + (k & 1) * SUB;
@@ -160,7 +177,7 @@ __device__ __forceinline__ bf16x8 tn_frag_opaque(const char* tile, int mb, int c
 // fragment q of the half-step in `slot`: q = 0..7 dY (32-row tile q >> 1, token rows 16 (q & 1) ..), q = 8..8+2*NJ-1 X
 __device__ __forceinline__ void read_frag(Frags& f, int q, const char* slot, int wm, int wn, int lane) {
   if (q < 8) f.a[q] = tn_frag_opaque(slot + wm * SUB, (q & 1) * 16, (q >> 1) * 32, lane);
-  else f.b[q - 8] = tn_frag_opaque(slot + PART + wn * SUB, (q & 1) * 16, ((q - 8) >> 1) * 32, lane);
+  else f.b[q - 8] = tn_frag_opaque(slot + PART + wn * SUB, (q & 1) * 16, ((q - 8) >> 1) * 32, lane);   // X columns 128 wn + ...
 }
 
 // The accumulators are pinned to AGPRs through the asm constraint (left to itself hipcc moves them to VGPRs and
@@ -288,20 +305,29 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
     ld_advance();
     HALF_STEP(f1, f0, 0, false);
     // ---- end of a K-step; at the end of a (tile, token piece) the accumulators are added to the gradient
-    //   acc[i][j][v] = dW[n0 + 128 wm + 32 i + 8 (v >> 2) + 4 (lane >> 5) + (v & 3)][k0 + 96 wn + 32 j + (lane & 31)]
+    //   acc[i][j][v] = dW[n0 + 128 wm + 32 i + 8 (v >> 2) + 4 (lane >> 5) + (v & 3)][k0 + 128 wn + 32 j + (lane & 31)]
     if (++cp_s == cp_item.se) {
       asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // MFMA results -> VALU reads: the asm MFMAs are opaque to the hazard pass
-      if (!(sch.dbg & 1)) {                           // tiles are whole: N % 256 == 0, K % 192 == 0 (launcher)
+      const bool whole = cp_tile.n0 + 256 <= cp_tile.N && cp_tile.k0 + TK <= cp_tile.K;
+      if (!(sch.dbg & 1)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int v = 0; v < 16; ++v) {
             int n = cp_tile.n0 + wm * 128 + i * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+            const bool nok = n < cp_tile.N;
             if (cp_tile.inter > 0)                    // dY columns are in the interleaved GeGLU order
               n = ((n & 63) < 32) ? 32 * (n >> 6) + (n & 31) : cp_tile.inter + 32 * (n >> 6) + (n & 31);
-            float* row = cp_tile.dw + (long)n * cp_tile.K + cp_tile.k0 + wn * 96 + (lane & 31);
+            const int k = cp_tile.k0 + wn * 128 + (lane & 31);
+            float* row = cp_tile.dw + (long)n * cp_tile.K + k;
+            if (whole) {                              // wave-uniform: no per-element predicates in the common case
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) atomicAdd(row + j * 32, acc[i][j][v]);
+              for (int j = 0; j < NJ; ++j) atomicAdd(row + j * 32, acc[i][j][v]);
+            } else {                                  // half a tile outside the matrix (N or K = 128 mod 256)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j)
+                if (nok && k + j * 32 < cp_tile.K) atomicAdd(row + j * 32, acc[i][j][v]);
+            }
           }
       }
       if (!cp_has_next) break;
@@ -328,11 +354,10 @@ int snx_launch_tn256(const TnGroup& g128, int M, hipStream_t st) {
   TnGroup g = g128;
   int run = 0;
   for (int p = 0; p < g.nprob; ++p) {
-    if ((g.N[p] % 256) || (g.K[p] % TK)) return SNX_E_SHAPE;
-    run += (g.N[p] / 256) * (g.K[p] / TK);
+    run += cdiv(g.N[p], 256) * cdiv(g.K[p], TK);
     g.tile_end[p] = run;
   }
-  if (run > NWG) return SNX_E_SHAPE;                  // caller falls back to the 128x128 kernel
+  if (run > NWG || M >= (1 << 27)) return SNX_E_SHAPE;   // caller falls back to the 128x128 kernel
   Sched s;
   s.ntiles = run;
   s.nsteps = cdiv(M, 2 * HS);
@@ -348,15 +373,17 @@ int snx_launch_tn256(const TnGroup& g128, int M, hipStream_t st) {
   // diagnostics: 1 = no atomics, 2 = no DMA, 4 = L2-resident operands
   static const int dbg = getenv("SNX_TN256_DBG") ? atoi(getenv("SNX_TN256_DBG")) : 0;
   s.dbg = dbg;
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[64] = {};                          // per device: the 160 KiB dynamic-LDS opt-in
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return SNX_E_ARG;
+  if (!attr[devid]) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, RING * SLOT);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               RING * SLOT);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr[devid] = true;
   }
   if (dbg & 2) hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(NWG), dim3(256), RING * SLOT, st, g, M, s);
   else hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(NWG), dim3(256), RING * SLOT, st, g, M, s);

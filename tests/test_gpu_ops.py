@@ -323,11 +323,10 @@ def test_gemm_tn_group_equals_separate_launches(dev):
 
 @pytest.mark.parametrize("M", [8192, 8263, 20000])
 def test_gemm_tn_256_form(dev, M):
-    """Token ranges of 8192 rows and more run the 256x192 persistent kernel (gemm_tn256.hip) when N % 256 == 0 and
-    K % 192 == 0: one long item per (token piece, tile) workgroup plus the stream-K tail workgroups, a ragged rest
-    of the token range (M % 64 rows, handed to the 128x128 kernel), the interleaved GeGLU row order, alone and
-    grouped; a group with a shape the form does not tile falls back as a whole.  Reference: fp32 matmul of the same
-    bf16 operands."""
+    """Token ranges of 8192 rows and more run the 256x256 persistent kernel (gemm_tn256.hip): one long item per
+    (token piece, tile) workgroup plus the stream-K tail workgroups, a ragged rest of the token range (M % 64 rows,
+    handed to the 128x128 kernel), tiles half outside the matrix (N or K = 128 mod 256), the interleaved GeGLU row
+    order, alone and grouped.  Reference: fp32 matmul of the same bf16 operands."""
     ops = _ops()
     g = torch.Generator().manual_seed(M)
     mk = lambda r, c, s=0.1: (torch.randn(r, c, generator=g) * s).to(dev).to(BF16)   # noqa: E731
@@ -356,7 +355,7 @@ def test_gemm_tn_256_form(dev, M):
 
 @pytest.mark.parametrize("M", [8192 + 64, 8192 + 37])
 def test_gemm_tn_256_layout(dev, M):
-    """Exact check of the 256x192 form: dY = a 0/1 selection pattern, so dW[n, :] = X[row(n), :] bit for bit
+    """Exact check of the 256x256 form: dY = a 0/1 selection pattern, so dW[n, :] = X[row(n), :] bit for bit
     (catches n/k swaps, sub-tile column maps, token-piece seams and the ragged rest)."""
     ops = _ops()
     N, K = 512, 768
