@@ -136,7 +136,19 @@ __global__ void token_weights_kernel(const unsigned short* __restrict__ rowpart,
   tw[t] = mask[t] != 0 ? log1pf(bits_to_f32(m)) : 0.f;
 }
 
-extern "C" size_t snx_splade_head_scratch_bytes(int32_t T, int32_t V) { return (size_t)cdiv(V, 128) * T * 2; }
+// 256x256 persistent form (decoder256.hip)
+size_t snx_dec256_table_bytes(int32_t T);
+int snx_dec256_rowtiles(int32_t V);                   // rows of the row-maximum array it writes (96-column half tiles)
+int snx_launch_decoder256(const void* Hd, const void* W, const float* bias, const int32_t* cu_seqlens,
+                          const int64_t* mask, float* sparse, uint32_t* keys, void* scratch, size_t rowpart_bytes,
+                          int32_t T, int32_t nseq, int32_t V, int32_t K, hipStream_t st);
+
+// row maxima [tiles, T] ushort (tiles = ceil(V / 128) for the 128x128 kernel, 2 ceil(V / 192) for the 256x192 form)
+// + the pre-pass tables of the latter
+extern "C" size_t snx_splade_head_scratch_bytes(int32_t T, int32_t V) {
+  const size_t tiles = (size_t)(cdiv(V, 128) > snx_dec256_rowtiles(V) ? cdiv(V, 128) : snx_dec256_rowtiles(V));
+  return ((tiles * T * 2 + 255) & ~(size_t)255) + snx_dec256_table_bytes(T);
+}
 
 // `finalize` = 0 skips the token_weights pass (used when several sequence groups of one token
 // buffer are processed by separate calls; the last call finalises all T rows).
@@ -148,6 +160,24 @@ extern "C" int snx_decoder_splade_fwd_ex(const void* Hd, const void* W, const fl
   if (!Hd || !W || !bias || !cu_seqlens || !mask || !sparse || !keys || !token_weights || !scratch) return SNX_E_ARG;
   if (T <= 0 || nseq <= 0 || V <= 0 || K <= 0 || (K % 64) || max_seqlen > 65535) return SNX_E_SHAPE;
   const int n_tiles = cdiv(V, 128);
+  // SNX_DEC256=0 keeps the 128x128 kernel; the 256x256 form wants enough rows to fill its tiles
+  static const int dec256 = getenv("SNX_DEC256") ? atoi(getenv("SNX_DEC256")) : 1;
+  static const int dec256_min_t = getenv("SNX_DEC256_MIN_T") ? atoi(getenv("SNX_DEC256_MIN_T")) : 2048;
+  if (dec256 && T >= dec256_min_t) {
+    const int rowtiles = snx_dec256_rowtiles(V);
+    const size_t tiles = (size_t)(n_tiles > rowtiles ? n_tiles : rowtiles);
+    const int rc = snx_launch_decoder256(Hd, W, bias, cu_seqlens, mask, sparse, keys, scratch, tiles * T * 2, T, nseq,
+                                         V, K, st);
+    if (rc != SNX_E_SHAPE) {
+      if (rc != SNX_OK) return rc;
+      if (finalize) {
+        hipLaunchKernelGGL(token_weights_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, (const unsigned short*)scratch,
+                           mask, token_weights, T, rowtiles);
+        SNX_CHECK_LAUNCH();
+      }
+      return SNX_OK;
+    }
+  }
   const long total_l = 8L * cdiv(cdiv(nseq, SNX_DEC_GROUP), 8) * SNX_DEC_GROUP * n_tiles;
   if (total_l > 0x7fffffffL) return SNX_E_SHAPE;
   const int total = (int)total_l;
