@@ -174,7 +174,19 @@ __device__ __forceinline__ TilePos tile_at(int k, int xcd, int j, int mtiles, in
 
 }  // namespace
 
+#ifdef SNX_GEMM_TRACE
+// diagnostics build: per workgroup shader-clock ticks in total / inside the epilogues, constant-clock ticks, tiles
+__device__ unsigned long long* g_dec256_trace = nullptr;
+extern "C" int snx_dec256_trace_set(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dec256_trace), &buf, sizeof(buf));
+}
+#endif
+
 __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
+#ifdef SNX_GEMM_TRACE
+  const unsigned long long tr_c0 = __builtin_amdgcn_s_memtime(), tr_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tr_epi = 0, tr_tiles = 0;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -300,15 +312,19 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
     // =================== end of a tile: SPLADE tail on the 256 x 256 logits in the accumulators ===================
     //   acc[i][j][v] = logit(row 128 wm + 32 i + 8 (v >> 2) + 4 (lane >> 5) + (v & 3), column 96 wn + 32 j + (lane & 31))
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // MFMA results -> VALU reads (asm MFMAs are opaque to the hazard pass)
+#ifdef SNX_GEMM_TRACE
+    const unsigned long long tr_e0 = __builtin_amdgcn_s_memtime();
+#endif
     {
       int lane = threadIdx.x & 63;                    // opaque copy: nothing of the lane arithmetic below may be hoisted
       asm volatile("" : "+v"(lane));                  // into the K loop, where every VGPR is taken
       const int hh = lane >> 5;
       const int col0 = cp_tile.nt * TV + wn * 96 + (lane & 31);
       const int t96 = cp_tile.nt * 2 + wn;            // row of the row-maximum array: one per 96-column half tile
+      // bias per column; columns past V get a bias that sends every logit to relu's zero
       float bcol[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bcol[j] = col0 + 32 * j < g.V ? rbf(g.bias[col0 + 32 * j]) : 0.f;
+      for (int j = 0; j < NJ; ++j) bcol[j] = col0 + 32 * j < g.V ? rbf(g.bias[col0 + 32 * j]) : -3.0e38f;
       // token rows of the 4 x 32 rows this lane stores row maxima for: lanes 16-31 / 48-63, lane & 15 = q <-> row
       // 8 (q >> 2) + 4 (lane >> 5) + (q & 3) of every sub-tile (loaded now, used at the end)
       const int myrr = 8 * ((lane & 15) >> 2) + 4 * hh + (lane & 3);
@@ -334,6 +350,17 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
           best[j] = 0u;
         }
       };
+      // maximum over the 32 lanes of each half (DPP inside the rows of 16 lanes, then lane 15 of the even rows
+      // into the odd rows): lanes 16-31 / 48-63 end up with it.  old = 0 is the identity of the unsigned maximum,
+      // which lets the DPP moves fold into v_max_u32_dpp.
+      auto half_max = [](uint32_t x) {
+        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true));   // row_half_mirror
+        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true));   // row_mirror
+        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1, 3
+        return x;
+      };
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (ent[i][0] < 0) break;                     // wave-uniform: past the last sub-tile
@@ -344,30 +371,31 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
         const uint32_t tagbase = 0xFFFFu - (uint32_t)(ent[i][2] + 4 * hh);
         uint32_t mine = 0u;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const uint32_t tag = tagbase - (uint32_t)(8 * (v >> 2) + (v & 3));
-          uint32_t rb = 0u;
+        for (int v = 0; v < 16; v += 2) {             // rows v and v + 1 of this lane: one bf16 pair per column tile
+          const uint32_t tag0 = tagbase - (uint32_t)(8 * (v >> 2) + (v & 3)), tag1 = tag0 - 1u;
+          uint32_t k0[NJ], k1[NJ];
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            const uint32_t bits = col0 + 32 * j < g.V ? bf16_bits(fmaxf(acc[i][j][v] + bcol[j], 0.f)) : 0u;
-            const uint32_t key = (bits << 16) | tag;
-            best[j] = key > best[j] ? key : best[j];
-            rb = bits > rb ? bits : rb;
+            const bf16x2 pk = (bf16x2){f2bf(fmaxf(acc[i][j][v] + bcol[j], 0.f)), f2bf(fmaxf(acc[i][j][v + 1] + bcol[j], 0.f))};
+            const uint32_t w = __builtin_bit_cast(uint32_t, pk);
+            k0[j] = (w << 16) | tag0;                 // key = value bits << 16 | 0xFFFF - list position
+            k1[j] = (w & 0xFFFF0000u) | tag1;
+            best[j] = max(best[j], max(k0[j], k1[j]));   // tag0 > tag1: the earlier row wins a tie
           }
-          // row maximum over this wave's 128 columns (the 32 lanes of one half hold one row): DPP butterfly inside
-          // each row of 16 lanes, then lane 15 of the even rows into the odd rows -> lanes 16-31 / 48-63 hold it
-          rb = max(rb, (uint32_t)__builtin_amdgcn_update_dpp((int)rb, (int)rb, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-          rb = max(rb, (uint32_t)__builtin_amdgcn_update_dpp((int)rb, (int)rb, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-          rb = max(rb, (uint32_t)__builtin_amdgcn_update_dpp((int)rb, (int)rb, 0x141, 0xF, 0xF, false));  // row_half_mirror
-          rb = max(rb, (uint32_t)__builtin_amdgcn_update_dpp((int)rb, (int)rb, 0x140, 0xF, 0xF, false));  // row_mirror
-          rb = max(rb, (uint32_t)__builtin_amdgcn_update_dpp((int)rb, (int)rb, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1, 3
-          mine = (lane & 15) == v ? rb : mine;
-          __builtin_amdgcn_sched_barrier(0);          // keep the accumulator reads of the next row behind this one's math
+          // a row's keys share their tag, so the row maximum of the keys is (max value bits) << 16 | tag
+          const uint32_t r0 = half_max(max(max(k0[0], k0[1]), k0[2])), r1 = half_max(max(max(k1[0], k1[1]), k1[2]));
+          mine = (lane & 15) == v ? r0 : mine;
+          mine = (lane & 15) == v + 1 ? r1 : mine;
+          if ((v & 6) == 6) __builtin_amdgcn_sched_barrier(0);   // bound the window: four rows' worth of temporaries
         }
-        if (tok[i] >= 0) g.rowpart[(long)t96 * g.T + tok[i]] = (unsigned short)mine;
+        if (tok[i] >= 0) g.rowpart[(long)t96 * g.T + tok[i]] = (unsigned short)(mine >> 16);
       }
       flush(cur_seq);
     }
+#ifdef SNX_GEMM_TRACE
+    tr_epi += __builtin_amdgcn_s_memtime() - tr_e0;
+    ++tr_tiles;
+#endif
     // next tile of the MFMA stream
     {
       TilePos t;
@@ -388,6 +416,15 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
     }
   }
 #undef HALF_STEP
+#ifdef SNX_GEMM_TRACE
+  if (threadIdx.x == 0 && g_dec256_trace) {
+    unsigned long long* o = g_dec256_trace + 4l * blockIdx.x;
+    o[0] = __builtin_amdgcn_s_memtime() - tr_c0;
+    o[1] = __builtin_amdgcn_s_memrealtime() - tr_r0;
+    o[2] = tr_epi;
+    o[3] = tr_tiles;
+  }
+#endif
 }
 
 // sizes of the pre-pass tables behind the row maxima in the scratch buffer (snx_splade_head_scratch_bytes adds them)
