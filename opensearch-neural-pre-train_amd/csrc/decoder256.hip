@@ -239,6 +239,10 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
   int ld_h = 0, ld_slot = 0;                          // half-step inside the tile, ring slot
   bool ld_more = true;                                // the stream has not reached its end (then it parks)
   auto issue = [&](int i) {                           // DMA instruction pair i (0..3) of the stream's half-step
+#ifdef SNX_DEC256_NODMA                               // diagnostics build: the K loop without its LDS-DMA traffic
+    if (i == 3) ld_slot = ld_slot + 1 == RING ? 0 : ld_slot + 1;
+    return;
+#endif
     const char* ba = (const char*)g.Hd + ld_h * 64;
     const char* bb = (const char*)g.W + ld_h * 64;
     char* s0 = smem + ld_slot * SLOT;
