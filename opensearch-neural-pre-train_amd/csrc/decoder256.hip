@@ -307,7 +307,29 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
   } while (0)
 
   int cp_h = 0;                                       // half-step of the MFMA stream inside its tile (even here)
+  // what the epilogue reads from memory (bias, token rows of the row maxima) is requested two half-steps before it:
+  // the vm queue returns in order, and behind four half-steps of DMA a load issued in the epilogue itself took
+  // about 3,000 cycles to come back
+  float pre_bias[NJ] = {0.f, 0.f, 0.f};
+  int pre_tok[4] = {-1, -1, -1, -1};
   while (true) {
+    if (cp_h + 2 >= nh) {
+      int lane = threadIdx.x & 63;                    // opaque copy (see the epilogue)
+      asm volatile("" : "+v"(lane));
+      const int col0 = cp_tile.nt * TV + wn * 96 + (lane & 31);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) pre_bias[j] = col0 + 32 * j < g.V ? g.bias[col0 + 32 * j] : -3.0e38f;
+      const int myrr = 8 * ((lane & 15) >> 2) + 4 * (lane >> 5) + (lane & 3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sub = cp_tile.mt * 8 + wm * 4 + i;
+        pre_tok[i] = -1;
+        if (sub < nsub) {
+          const i32x4 e = g.subtab[sub];
+          if ((lane & 16) && myrr < e[3]) pre_tok[i] = e[1] + g.list[e[1] + e[2] + myrr];
+        }
+      }
+    }
     if (cp_h == 0) HALF_STEP(f0, f1, true);
     else HALF_STEP(f0, f1, false);
     HALF_STEP(f1, f0, false);
@@ -328,17 +350,16 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
       // bias per column; columns past V get a bias that sends every logit to relu's zero
       float bcol[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bcol[j] = col0 + 32 * j < g.V ? rbf(g.bias[col0 + 32 * j]) : -3.0e38f;
-      // token rows of the 4 x 32 rows this lane stores row maxima for: lanes 16-31 / 48-63, lane & 15 = q <-> row
-      // 8 (q >> 2) + 4 (lane >> 5) + (q & 3) of every sub-tile (loaded now, used at the end)
-      const int myrr = 8 * ((lane & 15) >> 2) + 4 * hh + (lane & 3);
+      for (int j = 0; j < NJ; ++j) bcol[j] = rbf(pre_bias[j]);
+      // token rows of the 4 x 32 rows this lane stores row maxima for (lanes 16-31 / 48-63, lane & 15 = q <-> row
+      // 8 (q >> 2) + 4 (lane >> 5) + (q & 3) of every sub-tile): requested before the last two half-steps
       int tok[4];
       i32x4 ent[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int sub = cp_tile.mt * 8 + wm * 4 + i;
         ent[i] = sub < nsub ? g.subtab[sub] : (i32x4){-1, 0, 0, 0};
-        tok[i] = ((lane & 16) && myrr < ent[i][3]) ? ent[i][1] + g.list[ent[i][1] + ent[i][2] + myrr] : -1;
+        tok[i] = pre_tok[i];
       }
       uint32_t best[NJ] = {0u, 0u, 0u};
       int cur_seq = -1;
