@@ -238,20 +238,26 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
   offsets(ld_tile, ld_oa, ld_ob);
   int ld_h = 0, ld_slot = 0;                          // half-step inside the tile, ring slot
   bool ld_more = true;                                // the stream has not reached its end (then it parks)
-  auto issue = [&](int i) {                           // DMA instruction pair i (0..3) of the stream's half-step
+  // DMA instruction n (0..6: Hd rows 16 (n >> 1) .. for even n < 7... see below) of the stream's half-step, ONE per
+  // MFMA gap (its issue holds the wave for 60-70 cycles, of which the MFMA in flight covers 32): n = 0, 2, 4, 6 are
+  // the four Hd instructions, n = 1, 3, 5 the three W_E instructions.
+  auto issue = [&](int n) {
+    const int i = n >> 1;
 #ifdef SNX_DEC256_NODMA                               // diagnostics build: the K loop without its LDS-DMA traffic
-    if (i == 3) ld_slot = ld_slot + 1 == RING ? 0 : ld_slot + 1;
+    if (n == 6) ld_slot = ld_slot + 1 == RING ? 0 : ld_slot + 1;
     return;
 #endif
-    const char* ba = (const char*)g.Hd + ld_h * 64;
-    const char* bb = (const char*)g.W + ld_h * 64;
     char* s0 = smem + ld_slot * SLOT;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(ba + ld_oa[i]),
-                                     LDS_PTR(s0 + (wave >> 1) * SUBT + ((wave & 1) * 64 + i * 16) * 64), 16, 0, 0);
-    if (i < 3)
+    if (!(n & 1)) {
+      const char* ba = (const char*)g.Hd + ld_h * 64;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ba + ld_oa[i]),
+                                       LDS_PTR(s0 + (wave >> 1) * SUBT + ((wave & 1) * 64 + i * 16) * 64), 16, 0, 0);
+    } else {
+      const char* bb = (const char*)g.W + ld_h * 64;
       __builtin_amdgcn_global_load_lds(GLB_PTR(bb + ld_ob[i]),
                                        LDS_PTR(s0 + PART + (wave >> 1) * SUBW + ((wave & 1) * 48 + i * 16) * 64), 16, 0, 0);
-    if (i == 3) ld_slot = ld_slot + 1 == RING ? 0 : ld_slot + 1;
+    }
+    if (n == 6) ld_slot = ld_slot + 1 == RING ? 0 : ld_slot + 1;
   };
   auto ld_advance = [&]() {                           // next half-step; at the end of the stream: park on the last one
     if (ld_h + 1 < nh) {
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
 #pragma unroll 1
   for (int h = 0; h < RING; ++h) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue(i);
+    for (int n = 0; n < 7; ++n) issue(n);
     ld_advance();
   }
   asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
@@ -287,8 +293,8 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
   int rd_slot = 1;
   auto next_rd = [&]() { rd_slot = rd_slot + 1 == RING ? 0 : rd_slot + 1; };
 
-  // one half-step, no branch (gemm_tn256.hip): 24 MFMAs, the 7 DMA instructions behind MFMAs 0..3, the 14 fragment
-  // reads of the next half-step behind MFMAs 4..17
+  // one half-step, no branch (gemm_tn256.hip): 24 MFMAs, the 7 DMA instructions behind MFMAs 0..6, the 14 fragment
+  // reads of the next half-step behind MFMAs 7..20
 #define HALF_STEP(cur, nxt, FIRST)                                                              \
   do {                                                                                          \
     WAIT_VM(21);                                                                                \
@@ -298,8 +304,8 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
       const int h = m / (4 * NJ), i = (m / NJ) & 3, j = m % NJ;                                 \
       if (FIRST && h == 0) mfma_pinned_first(acc[i][j], cur.a[2 * i], cur.b[2 * j]);            \
       else mfma_pinned(acc[i][j], cur.a[2 * i + h], cur.b[2 * j + h]);                          \
-      if (m < 4) issue(m);                                                                      \
-      if (m >= 4 && m < 4 + 8 + 2 * NJ) read_frag(nxt, m - 4, rs, wm, wn, lane);                \
+      if (m < 7) issue(m);                                                                      \
+      if (m >= 7 && m < 7 + 8 + 2 * NJ) read_frag(nxt, m - 7, rs, wm, wn, lane);                \
     }                                                                                           \
     WAIT_LGKM0();                                                                               \
     next_rd();                                                                                  \

@@ -131,17 +131,22 @@ __device__ __forceinline__ LaneOff lane_offsets(const Tile& t, int wave, int lan
   return o;
 }
 
-// DMA instruction pair k (0..3) of the half-step starting at token tok0 into `slot`: rows 8w + 4(k >> 1) .. +3 of
+// DMA instruction k8 (0..7; pair k8 >> 1: dY then X) of the half-step starting at token tok0 into `slot`: rows 8w + 4(k >> 1) .. +3 of
 // sub-tile (k & 1) of the dY slice and of the X slice.  8 DMA instructions per wave and half-step, no branches.  The
 // launcher hands this kernel whole K-steps only (M % 64 == 0; the ragged rest goes to the 128x128 kernel).
-__device__ __forceinline__ void request_pair(const Tile& t, const LaneOff& o, int tok0, char* slot, int wave, int k) {
-  const int a2 = ((k & 1) && t.n0 + 128 < t.N) ? 256 : 0, b2 = ((k & 1) && t.k0 + 128 < t.K) ? 256 : 0;
-  const char* ba = (const char*)(t.dy + (long)tok0 * t.N) + a2;
-  const char* bb = (const char*)(t.x + (long)tok0 * t.K) + b2;
+__device__ __forceinline__ void request_one(const Tile& t, const LaneOff& o, int tok0, char* slot, int wave, int k8) {
+  const int k = k8 >> 1;                              // pair index: rows 8 wave + 4 (k >> 1) .., sub-tile k & 1
   char* d = slot + (wave * 8 + (k >> 1) * 4) * 256 + (k & 1) * SUB;
   // (default cache policy: nt loads measured no faster here, 489 vs 482 us per layer group)
-  __builtin_amdgcn_global_load_lds(GLB_PTR(ba + o.a[k >> 1]), LDS_PTR(d), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(GLB_PTR(bb + o.b[k >> 1]), LDS_PTR(d + PART), 16, 0, 0);
+  if (!(k8 & 1)) {
+    const int a2 = ((k & 1) && t.n0 + 128 < t.N) ? 256 : 0;
+    const char* ba = (const char*)(t.dy + (long)tok0 * t.N) + a2;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(ba + o.a[k >> 1]), LDS_PTR(d), 16, 0, 0);
+  } else {
+    const int b2 = ((k & 1) && t.k0 + 128 < t.K) ? 256 : 0;
+    const char* bb = (const char*)(t.x + (long)tok0 * t.K) + b2;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(bb + o.b[k >> 1]), LDS_PTR(d + PART), 16, 0, 0);
+  }
 }
 
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -223,16 +228,17 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
   LaneOff ld_off = lane_offsets(ld_tile, wave, lane);
   int ld_s = ld_item.sb, cp_s = cp_item.sb;
   int ld_slot = 0;
-  // DMA instruction pair k (0..3) of one half-step of the request stream: sub-tile (k & 1) of dY and of X ... see
-  // request_pair; after the fourth pair the stream's slot moves on
-  auto issue = [&](int half, int k) {
+  // DMA instruction k8 (0..7) of one half-step of the request stream (see request_one); after the eighth the stream's
+  // slot moves on.  ONE per MFMA gap: the issue of an LDS-DMA instruction holds the wave for 60-70 cycles, of which
+  // the MFMA in flight covers 32.
+  auto issue = [&](int half, int k8) {
     if (!NODMA)
-      request_pair(ld_tile, ld_off, (sch.dbg & 4) ? 0 : ld_s * 64 + half * HS, smem + ld_slot * SLOT, wave, k);
-    if (k == 3) ld_slot = ld_slot + 1 == RING ? 0 : ld_slot + 1;
+      request_one(ld_tile, ld_off, (sch.dbg & 4) ? 0 : ld_s * 64 + half * HS, smem + ld_slot * SLOT, wave, k8);
+    if (k8 == 7) ld_slot = ld_slot + 1 == RING ? 0 : ld_slot + 1;
   };
   auto issue_all = [&](int half) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) issue(half, k);
+    for (int k = 0; k < 8; ++k) issue(half, k);
   };
   // ... and the stream moves on to its next K-step.  At its end it PARKS on its last K-step: the K loop keeps
   // requesting (no branch in its body); a request always goes into the ring slot whose fragments are already in
@@ -267,8 +273,8 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
 
   auto next_rd = [&]() { rd_slot = rd_slot + 1 == RING ? 0 : rd_slot + 1; };
   // One half-step: 8 * NJ MFMAs (32x32x16: 4 x NJ tiles, two 16-token halves) on `cur`; between them (source order =
-  // issue order, see mfma_pinned) the 8 DMA instructions of the request stream behind MFMAs 0..3 and the 8 + 2 NJ
-  // fragments of the next half-step (2 ds_read_b64_tr_b16 each) behind MFMAs 4...  A 32x32x16 MFMA occupies the
+  // issue order, see mfma_pinned) the 8 DMA instructions of the request stream behind MFMAs 0..7 and the 8 + 2 NJ
+  // fragments of the next half-step (2 ds_read_b64_tr_b16 each) behind MFMAs 8...  A 32x32x16 MFMA occupies the
   // matrix pipe for 32 cycles and the wave's issue for 8: 24 cycles per gap for other instructions (with 16x16x32
   // MFMAs, 8 cycles per gap, a half-step took 1312 instead of 768 cycles).  The body has NO branch (one s_cbranch
   // per gap cost the single wave of a SIMD 64 cycles per MFMA instead of 32): requests and reads are unconditional
@@ -282,8 +288,8 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
       const int h = m / (4 * NJ), i = (m / NJ) & 3, j = m % NJ;   /* token half, dY tile, X tile */ \
       if (FIRST && h == 0) mfma_pinned_first(acc[i][j], cur.a[2 * i], cur.b[2 * j]);            \
       else mfma_pinned(acc[i][j], cur.a[2 * i + h], cur.b[2 * j + h]);                          \
-      if (m < 4) issue(half, m);                                                                \
-      if (m >= 4 && m < 4 + 8 + 2 * NJ) read_frag(nxt, m - 4, rs, wm, wn, lane);                \
+      if (m < 8) issue(half, m);                                                                \
+      if (m >= 8 && m < 8 + 8 + 2 * NJ) read_frag(nxt, m - 8, rs, wm, wn, lane);                \
     }                                                                                           \
     WAIT_LGKM0();                                                                               \
     next_rd();                                                                                  \
