@@ -1,16 +1,18 @@
-// Fused MLM-decoder GEMM + SPLADE tail, 256x256 persistent form (same contract as decoder_splade_kernel in
+// Fused MLM-decoder GEMM + SPLADE tail, 256x192 persistent form (same contract as decoder_splade_kernel in
 // splade_head.hip: hf modeling_modernbert.py:550 + ref:src/model/splade_modern.py:76-86).
 //
 //   key[b, v]   = max over the valid rows s of sequence b of  bf16bits(relu(Hd[b,s,:] . W[v,:] + bias[v])) << 16 | 0xFFFF - s
-//   sparse[b,v] = log1p(value(key));   rowpart[nt, t] = max over the 256 columns of vocab tile nt of the value bits
+//   sparse[b,v] = log1p(value(key));   rowpart[2 nt + wn, t] = max over the 96 columns of half tile (nt, wn) of the value bits
 //
 // The 128x128 kernel (one workgroup per (sequence, vocab tile), two per CU) runs at 0.27 of the MFMA peak: K = 768
 // gives every 128-row chunk a pipeline start-up of its own, and the operand tiles cross the L2 -> LDS path at 65
 // FLOP per byte.  This form reuses the main loop of gemm_tn256.hip (one 4-wave workgroup per CU, one wave per SIMD,
-// 128x128 wave tiles = 4x4 accumulators of v_mfma_f32_32x32x16_bf16 pinned to all 256 AGPRs, a five-slot LDS-DMA
-// ring over all 160 KiB of LDS that never drains between tiles, no branch inside the K loop) for operands that are
-// both K-contiguous: a half-step is 256 rows x 32 k of Hd and of W_E, rows of 64 B in LDS with the 16-B chunk
-// index XOR-swizzled by (row >> 2) & 3 (conflict-free ds_read_b128 in the 32x32x16 operand pattern).
+// accumulators of v_mfma_f32_32x32x16_bf16 pinned to AGPRs, a five-slot LDS-DMA ring that never drains between
+// tiles, no branch inside the K loop) for operands that are both K-contiguous: a half-step is 256 rows x 32 k of Hd
+// and 192 rows x 32 k of W_E (28 KiB), rows of 64 B in LDS with the 16-B chunk index XOR-swizzled by (row >> 2) & 3
+// (conflict-free ds_read_b128 in the 32x32x16 operand pattern).  Wave tile 128 x 96 = 4 x 3 accumulator tiles: 192
+// of the 256 AGPRs; with all 256 taken hipcc spills inside the K loop, and a spill store right behind one of the asm
+// LDS reads saves the register before its data has arrived (seen as intermittently wrong rows).
 //
 // Rows.  A tile's 256 rows are eight SUB-TILES of 32 rows, each inside ONE sequence: a pre-pass compacts the valid
 // rows of every sequence (any mask) into a list, cuts it into sub-tiles and pads the last one of a sequence by
@@ -20,7 +22,13 @@
 // Sequences meet in the key array through atomicMax (a sequence may span several tiles and both wave rows).
 //
 // Tiles are dealt in blocks of 4 (rows) x 8 (vocab) to the 32 workgroups of an XCD (blockIdx & 7), which walk K
-// in step: the 12 operand panels of a block are shared through that XCD's L2.
+// in step: the 12 operand panels of a block are shared through that XCD's L2 (5.2 GB of fabric reads per launch of
+// the bench's 192 sequences against 25 GB of LDS-DMA traffic; the 128x128 kernel: 5.7 GB).
+//
+// Measured (64 x 64 + 128 x 256 tokens, V = 50,000, in-kernel stamps of a -DSNX_GEMM_TRACE build, tools/gpu_decbench.py):
+// 3.45 ms = 822 TFLOP/s (128x128 kernel: 4.16 ms); per tile 46.9k cycles = 24 half-steps of 1,514 (768 of them MFMA; 1,042
+// without the DMA instructions, whose issue holds the single wave of a SIMD 60-70 cycles each) + 10.5k of epilogue.
+// A variant with 128-B rows (K = 64 per slot, two slots) was no faster: the L2 -> LDS path is not what bounds it.
 #include "common.h"
 #include "snx.h"
 
