@@ -170,8 +170,10 @@ int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32_t M, int32
 int snx_gemm_tn_accum_interleaved(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K,
                                   hipStream_t stream);
 /* up to 4 weight-gradient problems over the SAME M token rows (the four Linears of one encoder layer, whose
- * nn.Linear backward torch runs as four GEMMs) in one launch: the concatenated output tiles fill whole rounds of
- * the resident workgroups (csrc/gemm.hip). */
+ * nn.Linear backward torch runs as four GEMMs) in one launch.  From 8,192 token rows on: the 256x256 persistent kernel
+ * (csrc/gemm_tn256.hip: one workgroup per CU, one flush of float atomics per workgroup); below, and for the ragged
+ * rest of M % 64 rows: the concatenated 128x128 output tiles fill whole rounds of the resident workgroups
+ * (csrc/gemm.hip).  N, K multiples of 128. */
 typedef struct snx_tn_problem {
   const void* dY; /* [M, N] bf16 */
   const void* X;  /* [M, K] bf16 */
@@ -225,7 +227,10 @@ int snx_attn_bwd_ex(const void* qkv, const void* out, const void* dout, const fl
                     const int32_t* pos, const int32_t* groups, int32_t T, int32_t nseq, int32_t max_seqlen,
                     int32_t heads, int32_t head_dim, int32_t window, hipStream_t stream);
 
-/* Tied decoder GEMM + SPLADE tail fused (hf:550 + ref:src/model/splade_modern.py:76-86). */
+/* Tied decoder GEMM + SPLADE tail fused (hf:550 + ref:src/model/splade_modern.py:76-86).  From 2,048 token rows on
+ * the 256x192 persistent kernel (csrc/decoder256.hip: it zeroes `keys`, builds its row tables in `scratch` and ends
+ * with a finalize pass), below the 128x128 kernel (csrc/splade_head.hip); same outputs, any mask.  `scratch`:
+ * snx_splade_head_scratch_bytes(T, V) bytes (T = rows of the whole token buffer). */
 size_t snx_splade_head_scratch_bytes(int32_t T, int32_t V);
 int snx_decoder_splade_fwd_ex(const void* Hd, const void* W, const float* bias, const int32_t* cu_seqlens,
                               const int64_t* mask, float* sparse, uint32_t* keys, float* token_weights, void* scratch,
