@@ -301,19 +301,25 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
   int rd_slot = 1;
   auto next_rd = [&]() { rd_slot = rd_slot + 1 == RING ? 0 : rd_slot + 1; };
 
-  // one half-step, no branch (gemm_tn256.hip): 24 MFMAs, the 7 DMA instructions behind MFMAs 0..6, the 14 fragment
-  // reads of the next half-step behind MFMAs 7..20
+  // one half-step, no branch (gemm_tn256.hip): 24 MFMAs, the barrier behind the first four, the 7 DMA instructions behind
+  // MFMAs 4..10, the 14 fragment reads of the next half-step behind MFMAs 11..22
 #define HALF_STEP(cur, nxt, FIRST)                                                              \
   do {                                                                                          \
-    WAIT_VM(21);                                                                                \
-    BARRIER();                                                                                  \
     const char* rs = smem + rd_slot * SLOT;                                                     \
     _Pragma("unroll") for (int m = 0; m < 8 * NJ; ++m) {                                        \
       const int h = m / (4 * NJ), i = (m / NJ) & 3, j = m % NJ;                                 \
+      if (m == 4) {              /* four MFMAs in front of the barrier: the wait runs under them */ \
+        WAIT_VM(21);                                                                            \
+        BARRIER();                                                                              \
+      }                                                                                         \
       if (FIRST && h == 0) mfma_pinned_first(acc[i][j], cur.a[2 * i], cur.b[2 * j]);            \
       else mfma_pinned(acc[i][j], cur.a[2 * i + h], cur.b[2 * j + h]);                          \
-      if (m < 7) issue(m);                                                                      \
-      if (m >= 7 && m < 7 + 8 + 2 * NJ) read_frag(nxt, m - 7, rs, wm, wn, lane);                \
+      if (m >= 4 && m < 11) issue(m - 4);                                                       \
+      if (m >= 11 && m < 23) read_frag(nxt, m - 11, rs, wm, wn, lane);                          \
+      if (m == 22) {                                                                            \
+        read_frag(nxt, 12, rs, wm, wn, lane);                                                   \
+        read_frag(nxt, 13, rs, wm, wn, lane);                                                   \
+      }                                                                                         \
     }                                                                                           \
     WAIT_LGKM0();                                                                               \
     next_rd();                                                                                  \

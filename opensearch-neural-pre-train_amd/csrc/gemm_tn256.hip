@@ -279,17 +279,21 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
   // MFMAs, 8 cycles per gap, a half-step took 1312 instead of 768 cycles).  The body has NO branch (one s_cbranch
   // per gap cost the single wave of a SIMD 64 cycles per MFMA instead of 32): requests and reads are unconditional
   // -- past the end of the streams they re-request parked rows and read fragments nobody uses.
+  // PRE MFMAs go in front of the barrier: they need neither the new data nor a free slot, and the wait runs under them
+#define PRE 4
 #define HALF_STEP(cur, nxt, half, FIRST)                                                        \
   do {                                                                                          \
-    WAIT_VM(24);                                                                                \
-    BARRIER();                                                                                  \
     const char* rs = smem + rd_slot * SLOT;                                                     \
     _Pragma("unroll") for (int m = 0; m < 8 * NJ; ++m) {                                        \
       const int h = m / (4 * NJ), i = (m / NJ) & 3, j = m % NJ;   /* token half, dY tile, X tile */ \
+      if (m == PRE) {                                                                           \
+        WAIT_VM(24);                                                                            \
+        BARRIER();                                                                              \
+      }                                                                                         \
       if (FIRST && h == 0) mfma_pinned_first(acc[i][j], cur.a[2 * i], cur.b[2 * j]);            \
       else mfma_pinned(acc[i][j], cur.a[2 * i + h], cur.b[2 * j + h]);                          \
-      if (m < 8) issue(half, m);                                                                \
-      if (m >= 8 && m < 8 + 8 + 2 * NJ) read_frag(nxt, m - 8, rs, wm, wn, lane);                \
+      if (m >= PRE && m < PRE + 8) issue(half, m - PRE);                                        \
+      if (m >= PRE + 8 && m < PRE + 8 + 8 + 2 * NJ) read_frag(nxt, m - PRE - 8, rs, wm, wn, lane); \
     }                                                                                           \
     WAIT_LGKM0();                                                                               \
     next_rd();                                                                                  \
@@ -345,6 +349,7 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
     }
   }
 #undef HALF_STEP
+#undef PRE
 #ifdef SNX_GEMM_TRACE
   if (threadIdx.x == 0 && g_tn256_trace) {
     unsigned long long* o = g_tn256_trace + 4l * blockIdx.x;
