@@ -287,6 +287,51 @@ def test_decoder_splade_fwd(dev, B, S, V, K):
     assert agree.float().mean().item() > 0.999
 
 
+@pytest.mark.parametrize("B,S", [(6, 64), (24, 128)])
+def test_decoder_splade_fwd_irregular_masks(dev, B, S):
+    """Masks that are not right padding: holes, left padding, a single valid row in the middle and a fully masked
+    sequence -- the 256x192 kernel (B * S >= 2048) compacts the valid rows and reports sequence positions, the 128x128
+    kernel (small case) masks rows in its epilogue; both must give the masked reference and never pick a masked row."""
+    ops = _ops()
+    V, K = 1000, 256
+    T = B * S
+    g = torch.Generator().manual_seed(B * S)
+    mask = (torch.rand(B, S, generator=g) < 0.7).long()
+    mask[1, : S // 3] = 0                                   # left padding
+    mask[1, S // 3:] = 1
+    mask[2] = 0
+    mask[2, S // 2] = 1                                     # one valid row
+    mask[3] = 0                                             # fully masked
+    hd = torch.randn(T, K, generator=g).to(BF16).to(dev)
+    W = (torch.randn(V, K, generator=g) * 0.05).to(BF16).to(dev)
+    bias = (torch.randn(V, generator=g) * 0.3).to(dev)
+    cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
+    md = mask.to(dev)
+    sp, keys, tw = ops.decoder_splade_fwd(hd, W, bias, cu, md.reshape(-1), S)
+    logits = ((hd.float() @ W.float().t()) + bias.to(BF16).float()).to(BF16)
+    sc = torch.log1p(torch.relu(logits).float()).view(B, S, V) * md[:, :, None].float()
+    ref_sp, ref_tw = sc.max(dim=1).values, sc.max(dim=-1).values.reshape(T)
+    d = (sp - ref_sp).abs()
+    assert d.max().item() < 0.02 and (d > 1e-6).float().mean().item() < 0.02
+    dt = (tw - ref_tw).abs()
+    assert dt.max().item() < 0.02 and (dt > 1e-6).float().mean().item() < 0.03
+    assert (tw[md.reshape(-1) == 0] == 0).all()
+    assert (sp[3] == 0).all()
+    kk = keys.to(torch.int64) & 0xFFFFFFFF
+    val = ((kk >> 16).to(torch.int32) << 16).view(torch.float32)
+    assert torch.equal(torch.log1p(val), sp)
+    row = (0xFFFF - (kk & 0xFFFF)).clamp(max=S - 1)
+    pos = val > 0
+    assert (torch.gather(md, 1, row)[pos] == 1).all()      # the arg-max row is a valid row ...
+    relu_logits = torch.relu(logits).float().view(B, S, V)
+    at_row = torch.gather(relu_logits, 1, row.view(B, 1, V)).view(B, V)
+    assert ((at_row[pos] - val[pos]).abs() <= 2 ** -7 * val[pos]).all()   # ... that attains the maximum ...
+    same = (relu_logits == val.view(B, 1, V)) & md[:, :, None].bool()
+    first = torch.where(same.any(1), same.float().argmax(1), torch.zeros_like(row))
+    agree = (first == row) | ~pos | ((at_row - val).abs() > 0)
+    assert agree.float().mean().item() > 0.999             # ... and the first one that does
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 768, 256), (4096, 2304, 768), (777, 768, 1152), (200, 256, 384)])
 def test_gemm_tn_accum(dev, M, N, K):
     ops = _ops()
