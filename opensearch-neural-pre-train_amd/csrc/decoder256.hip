@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
 // sizes of the pre-pass tables behind the row maxima in the scratch buffer (snx_splade_head_scratch_bytes adds them)
 int snx_dec256_rowtiles(int32_t V) { return 2 * cdiv(V, TV); }
 
-size_t snx_dec256_table_bytes(int32_t T) { return (size_t)T * 4 + (size_t)T * 4 + ((size_t)T / 32 + T + 8) * 16 + 256; }
+size_t snx_dec256_table_bytes(int32_t T) { return (size_t)T * 4 + (size_t)T * 4 + 16 + ((size_t)T / 32 + T + 8) * 16 + 256; }
 
 int snx_launch_decoder256(const void* Hd, const void* W, const float* bias, const int32_t* cu_seqlens,
                           const int64_t* mask, float* sparse, uint32_t* keys, void* scratch, size_t rowpart_bytes,
@@ -485,7 +485,7 @@ int snx_launch_decoder256(const void* Hd, const void* W, const float* bias, cons
   char* base = (char*)scratch + ((rowpart_bytes + 255) & ~(size_t)255);
   int32_t* list = (int32_t*)base;
   int32_t* nvalid = list + T;
-  i32x4* subtab = (i32x4*)(nvalid + T);
+  i32x4* subtab = (i32x4*)(((uintptr_t)(nvalid + T) + 15) & ~(uintptr_t)15);   // 16-byte aligned for any T
   int32_t* hdr = (int32_t*)(subtab + ((size_t)T / 32 + T + 8));
   hipLaunchKernelGGL(dec256_rows_kernel, dim3(nseq), dim3(64), 0, st, cu_seqlens, mask, list, nvalid, nseq);
   SNX_CHECK_LAUNCH();

@@ -247,7 +247,7 @@ def test_attention_fwd(dev, S, window):
 # over two tiles (S = 300), short sequences sharing a tile (S = 40, 64), vocabulary edges (V = 777, 50000)
 @pytest.mark.parametrize("B,S,V,K", [(3, 64, 1000, 256), (4, 256, 1000, 768), (2, 200, 50000, 768), (5, 40, 777, 256),
                                      (2, 300, 640, 256), (12, 256, 1000, 768), (64, 40, 777, 256), (9, 300, 640, 256),
-                                     (10, 256, 50000, 768), (40, 64, 1024, 128)])
+                                     (10, 256, 50000, 768), (40, 64, 1024, 128), (33, 63, 640, 256)])
 def test_decoder_splade_fwd(dev, B, S, V, K):
     ops = _ops()
     T = B * S
