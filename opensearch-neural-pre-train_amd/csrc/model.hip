@@ -7,6 +7,8 @@
 #include "common.h"
 #include "snx.h"
 
+bool snx_dec256_takes(int32_t T);   // splade_head.hip
+
 namespace {
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -344,7 +346,8 @@ extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* par
     // get the decoder tile height that fits their length; groups = {n, (seq_begin, nseq, max_len)*n}.
     PROF(PC_DECODER_SPLADE, 2.0 * TH * V);
     int32_t one[4] = {1, 0, nseq, max_seqlen};
-    const int32_t* g = groups ? groups : one;
+    // the 256x192 decoder handles mixed lengths by itself: one call (one pre-pass, one tile schedule) for all groups
+    const int32_t* g = (groups && !snx_dec256_takes(T)) ? groups : one;
     for (int i = 0; i < g[0]; ++i) {
       const int sb = g[1 + 3 * i], ns = g[2 + 3 * i], ml = g[3 + 3 * i];
       if (sb < 0 || ns <= 0 || sb + ns > nseq || ml <= 0 || ml > max_seqlen) return SNX_E_ARG;

@@ -153,6 +153,14 @@ int snx_launch_decoder256(const void* Hd, const void* W, const float* bias, cons
                           const int64_t* mask, float* sparse, uint32_t* keys, void* scratch, size_t rowpart_bytes,
                           int32_t T, int32_t nseq, int32_t V, int32_t K, hipStream_t st);
 
+// SNX_DEC256=0 keeps the 128x128 kernel; the 256x192 form wants enough rows to fill its tiles.  (model.hip asks: the
+// 256x192 form takes all sequence groups of a pass in ONE call, the 128x128 kernel one call per group.)
+bool snx_dec256_takes(int32_t T) {
+  static const int dec256 = getenv("SNX_DEC256") ? atoi(getenv("SNX_DEC256")) : 1;
+  static const int dec256_min_t = getenv("SNX_DEC256_MIN_T") ? atoi(getenv("SNX_DEC256_MIN_T")) : 2048;
+  return dec256 && T >= dec256_min_t;
+}
+
 // row maxima [tiles, T] ushort (tiles = ceil(V / 128) for the 128x128 kernel, 2 ceil(V / 192) for the 256x192 form)
 // + the pre-pass tables of the latter
 extern "C" size_t snx_splade_head_scratch_bytes(int32_t T, int32_t V) {
@@ -170,10 +178,7 @@ extern "C" int snx_decoder_splade_fwd_ex(const void* Hd, const void* W, const fl
   if (!Hd || !W || !bias || !cu_seqlens || !mask || !sparse || !keys || !token_weights || !scratch) return SNX_E_ARG;
   if (T <= 0 || nseq <= 0 || V <= 0 || K <= 0 || (K % 64) || max_seqlen > 65535) return SNX_E_SHAPE;
   const int n_tiles = cdiv(V, 128);
-  // SNX_DEC256=0 keeps the 128x128 kernel; the 256x256 form wants enough rows to fill its tiles
-  static const int dec256 = getenv("SNX_DEC256") ? atoi(getenv("SNX_DEC256")) : 1;
-  static const int dec256_min_t = getenv("SNX_DEC256_MIN_T") ? atoi(getenv("SNX_DEC256_MIN_T")) : 2048;
-  if (dec256 && T >= dec256_min_t) {
+  if (snx_dec256_takes(T)) {
     const int rowtiles = snx_dec256_rowtiles(V);
     const size_t tiles = (size_t)(n_tiles > rowtiles ? n_tiles : rowtiles);
     const int rc = snx_launch_decoder256(Hd, W, bias, cu_seqlens, mask, sparse, keys, scratch, tiles * T * 2, T, nseq,
