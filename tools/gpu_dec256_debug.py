@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Structured-input check of the decoder kernels: Hd rows are one-hot at k = t % K and W[v, k] = k % 128 + 1, so the
+row maximum of token t must be (t % K) % 128 + 1 -- a wrong value names the row (or k chunk) that was read instead."""
 import os, sys
 sys.path.insert(0, "/root/repo/opensearch-neural-pre-train_amd")
 import torch
