@@ -49,6 +49,12 @@ def test_shape_validation_happens_on_the_host():
     assert fn("snx_param_count")(C.byref(d)) == 137
     assert fn("snx_weight_cache_bytes")(C.byref(d)) > 2 * 2 * 110_000_000
     assert fn("snx_model_workspace_bytes")(C.byref(d), 64 * 256, 64, 1) > fn("snx_model_workspace_bytes")(C.byref(d), 64 * 256, 64, 0)
+    # SPLADE-head scratch: row maxima for either decoder kernel (128-column tiles or 96-column half tiles) + the
+    # 256x192 kernel's row tables (valid-row list, counts, sub-tile table)
+    T, V = 36864, 50000
+    rows = max((V + 127) // 128, 2 * ((V + 191) // 192))
+    assert fn("snx_splade_head_scratch_bytes")(T, V) >= rows * T * 2 + 8 * T + 16 * (T // 32 + T)
+    assert fn("snx_splade_head_scratch_bytes")(7, 33) >= 2 * 7 * 2 + 8 * 7 + 16 * 7
     bad = EncoderGeometry(hidden_size=512, num_attention_heads=16).desc()            # head_dim 32
     assert fn("snx_param_count")(C.byref(bad)) == -1
     # grouped weight-gradient GEMM: 1..4 problems, N and K multiples of 128, non-null operands
