@@ -546,6 +546,21 @@ def test_train_epoch_vs_oracle_loop(dev, mode):
     train_epoch_case(dev, mode)
 
 
+def test_train_epoch_on_the_256_wide_kernels(dev):
+    """The trainer loop test above, in a child process with the thresholds of the two persistent kernels lowered (they
+    are read once per process) so that the small model's 500-odd packed token rows go through gemm_tn256.hip (with a
+    ragged rest of M % 64 rows on the 128x128 kernel and tiles half outside the 384- and 768-wide matrices) and
+    decoder256.hip: same loss, accumulated-gradient and parameter-value bounds."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SNX_TN256_MIN_M="128", SNX_DEC256_MIN_T="64")
+    root = os.path.dirname(os.path.dirname(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_model.py", "-q", "-x", "-m", "gpu", "-k",
+                        "test_train_epoch_vs_oracle_loop and native"], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_inference_encoder_matches_reference_postprocessing(dev):
     """`benchmark.encoders.NeuralSparseEncoderV33` (ref:benchmark/encoders.py:249-402): same methods / return types;
     its device-side top-k equals the oracle's restatement of `_encode_batch` applied to the model's own
