@@ -183,6 +183,13 @@ typedef struct snx_tn_problem {
   int32_t reserved;
 } snx_tn_problem;
 int snx_gemm_tn_accum_group(const snx_tn_problem* probs /*[host]*/, int32_t nprob, int32_t M, hipStream_t stream);
+/* Process-wide launch hint (host state, read at launch time): leave `n` CUs (0..128, rounded up to a multiple of 8)
+ * to other kernels.  The persistent weight-gradient kernel takes one whole CU per workgroup; while RCCL's channel
+ * workgroups run an overlapped gradient exchange (the role of DDP's reducer, ref:src/train/cli/train_v33_ddp.py:539-544)
+ * a 256-workgroup launch would run its last workgroups as a second wave, so it launches 256 - n instead (its
+ * schedule balances any count).  Results are unchanged up to fp32 summation order. */
+int snx_set_reserved_cus(int32_t n);
+int snx_get_reserved_cus(void);
 
 /* LayerNorm without bias (hf:61,312,314,420,487), fp32 in -> bf16 out. */
 int snx_ln_fwd(const float* h, const float* w, void* x_out, int32_t T, int32_t H, float eps, hipStream_t stream);

@@ -52,7 +52,7 @@ constexpr int SUB = HS * 256;        // one sub-tile: 32 tokens x 128 columns bf
 constexpr int PART = 2 * SUB;        // one operand slice: 32 tokens x 256 columns
 constexpr int SLOT = 2 * PART;       // dY slice + X slice = 32 KiB
 constexpr int RING = 5;              // 160 KiB
-constexpr int NWG = 256;
+constexpr int NWG = 256;              // one workgroup per CU; fewer while CUs are reserved (snx_set_reserved_cus)
 constexpr int TK = 256;              // X columns of an output tile (dY columns: 256)
 constexpr int NJ = 4;                // 32-column accumulator tiles per wave along X (4 along dY): wave tile 128 x 128
 
@@ -361,7 +361,20 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
 #endif
 }
 
+// CUs left to other kernels (RCCL's channel workgroups while a gradient bucket is being exchanged): this kernel's
+// workgroups take a whole CU each (160 KiB of LDS, one 512-register wave per SIMD), so with fewer than 256 free CUs
+// a 256-workgroup launch would run its last workgroups as a second wave -- twice the time.  The schedule below
+// balances any workgroup count (one long item per workgroup + a stream-K tail), so the launch simply shrinks.
+static int g_reserved_cus = 0;
+extern "C" int snx_set_reserved_cus(int32_t n) {
+  if (n < 0 || n > 128) return SNX_E_ARG;
+  g_reserved_cus = (n + 7) & ~7;                      // whole rounds of the 8 XCDs (the logical-id map needs nwg % 8 == 0)
+  return SNX_OK;
+}
+extern "C" int snx_get_reserved_cus() { return g_reserved_cus; }
+
 int snx_launch_tn256(const TnGroup& g128, int M, hipStream_t st) {
+  const int NWG = ::NWG - g_reserved_cus;
   TnGroup g = g128;
   int run = 0;
   for (int p = 0; p < g.nprob; ++p) {

@@ -43,6 +43,8 @@ SIGNATURES = {
     "snx_gemm_nt_geglu_bwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "snx_gemm_tn_accum_interleaved": (I32, [P, P, P, I32, I32, I32, P]),
     "snx_gemm_tn_accum_group": (I32, [P, I32, I32, P]),
+    "snx_set_reserved_cus": (I32, [I32]),
+    "snx_get_reserved_cus": (I32, []),
     "snx_cast_geglu_interleave": (I32, [P, P, P, I32, I32, P]),
     "snx_splade_head_scratch_bytes": (SZ, [I32, I32]),
     "snx_decoder_splade_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),

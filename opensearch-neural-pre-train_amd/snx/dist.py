@@ -76,19 +76,46 @@ class BucketedGradSync:
     The native backward runs as `n_buckets` consecutive unit ranges (include/snx.h
     snx_model_backward_units).  Buckets follow COMPLETION order, which is also address order in the flat
     gradient buffer (canonical parameter order = forward order): [tail + last layers] first, [first layers +
-    embeddings] last; each bucket is one contiguous slice -> one all-reduce(AVG) on the exchange stream, which
+    embeddings] last; each bucket is one contiguous slice -> one collective on the exchange stream, which
     the native call makes wait for the producers (launch stream and weight-gradient stream).  The compute
     stream never waits until `wait()` (before clip + AdamW).  xGMI is point-to-point: few large collectives
-    keep all 7 links busy, so the default is 4 buckets of ~120-230 MB rather than DDP's 25 MB."""
+    keep all 7 links busy, so the default is 4 buckets of ~120-230 MB rather than DDP's 25 MB.
 
-    def __init__(self, device, n_buckets: int = 4):
+    Which backward exchanges.  A micro-step may be ONE native backward (fused passes) or THREE (query /
+    positive / negative forwards, the reference's call pattern ref:train_v33_ddp.py:339-343 -> one reduction at
+    :364).  All of them add into the same flat buffer, so a slice may be reduced only by the LAST backward that
+    writes it: `arm()` opens a micro-step, every saving forward made while armed takes a token (`on_forward`),
+    every backward hands it back (`claim_backward`) and only the one that returns the last outstanding token
+    runs the bucketed exchange.  A backward whose forward predates `arm()` disarms (the caller's
+    `sync_gradients()` then reduces the whole buffer), and a backward that arrives between a finished exchange
+    and `wait()` raises: it would add local gradients to slices that are already averaged.
+
+    `mode`: "allreduce" (one all_reduce(AVG) per bucket, RCCL picks the algorithm) or "rs_ag" (reduce-scatter +
+    all-gather in place: each rank reduces 1/world of the bucket over its 7 direct xGMI links, then the shards
+    are gathered -- the direct, non-ring form).  Env SNX_GRAD_EXCHANGE selects it."""
+
+    def __init__(self, device, n_buckets: int = 4, mode: Optional[str] = None):
         self.device = torch.device(device)
         self.n_buckets = max(1, int(n_buckets))
+        self.mode = mode or os.environ.get("SNX_GRAD_EXCHANGE", "allreduce")
+        if self.mode not in ("allreduce", "rs_ag"):
+            raise ValueError(f"SNX_GRAD_EXCHANGE must be 'allreduce' or 'rs_ag', got {self.mode!r}")
         # CPU tensors (gloo, host-logic tests) have no streams: the collectives then simply run in program order
         self.stream = exchange_stream(self.device) if self.device.type == "cuda" else None
         self.armed = False
         self.pending = False
+        self.epoch = 0                                   # one per arm(): tokens of older forwards do not count
+        self.outstanding = 0                             # saving forwards of this micro-step not yet back-propagated
         self.slices: List[Tuple[int, int]] = []          # what the last armed backward reduced (tests)
+        self.log: List[tuple] = []                       # ("fwd"|"bwd"|"exchange"|"reduce", ...) call order (tests)
+        self.keep_log = os.environ.get("SNX_GRAD_SYNC_LOG", "0") == "1"
+        # CUs the persistent weight-gradient kernel leaves to RCCL's channel workgroups while the exchange overlaps
+        # the backward (include/snx.h snx_set_reserved_cus); 0 = none
+        self.reserved_cus = int(os.environ.get("SNX_EXCHANGE_RESERVED_CUS", "32"))
+
+    def _note(self, *ev) -> None:
+        if self.keep_log:
+            self.log.append(ev)
 
     def unit_ranges(self, n_units: int) -> List[Tuple[int, int]]:
         """Split units [0, n_units) into n_buckets consecutive ranges; the tail unit rides with the first
@@ -100,19 +127,96 @@ class BucketedGradSync:
         return [(cuts[i], cuts[i + 1]) for i in range(nb) if cuts[i] < cuts[i + 1]]
 
     def arm(self, on: bool = True) -> None:
-        """The NEXT backward is the last of its accumulation window: exchange while it runs."""
+        """Opens a micro-step.  on=True: it is the last of its accumulation window -- the last backward of the
+        forwards made from here on exchanges while it runs."""
+        if self.pending:
+            raise RuntimeError("arm() between an overlapped gradient exchange and sync_gradients(): the averaged "
+                               "gradients have not been consumed yet")
         self.armed = bool(on) and active()
+        self.epoch += 1
+        self.outstanding = 0
         if self.armed:
             self.slices = []
 
+    def on_forward(self) -> Optional[int]:
+        """A forward that saves for backward, made while armed: returns the token its backward hands back."""
+        if not self.armed:
+            return None
+        self.outstanding += 1
+        self._note("fwd", self.epoch, self.outstanding)
+        return self.epoch
+
+    def claim_backward(self, token: Optional[int]) -> bool:
+        """Called by every backward that adds into the flat buffer.  True: this is the last backward of the
+        armed micro-step -> run the bucketed exchange inside it."""
+        if self.pending:
+            raise RuntimeError("a backward ran after the overlapped gradient exchange of this window and before "
+                               "sync_gradients(): its gradients would be added to already averaged slices")
+        if not self.armed:
+            self._note("bwd", token, False)
+            return False
+        if token != self.epoch:
+            # graph built before arm() (a custom loop that armed too late): no overlap, reduce everything later
+            self.armed = False
+            self._note("bwd", token, False)
+            return False
+        self.outstanding -= 1
+        last = self.outstanding == 0
+        self._note("bwd", token, last)
+        return last
+
+    def _reduce(self, t: torch.Tensor) -> None:
+        """Average the 1-D fp32 slice `t` over ranks in place (current stream / program order)."""
+        w = world()
+        gpu = t.is_cuda
+        if self.mode == "rs_ag" and t.numel() >= w:
+            chunk = t.numel() // w
+            body, r = t[:chunk * w], rank()
+            mine = body[r * chunk:(r + 1) * chunk]
+            if gpu:                                      # RCCL: in-place forms (shard r of the buffer is rank r's)
+                dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.AVG)
+                dist.all_gather_into_tensor(body, mine)
+            else:                                        # gloo has neither: one reduce per owner, then all_gather
+                for o in range(w):
+                    dist.reduce(body[o * chunk:(o + 1) * chunk], dst=o, op=dist.ReduceOp.SUM)
+                mine.div_(w)
+                parts = [torch.empty_like(mine) for _ in range(w)]
+                dist.all_gather(parts, mine.clone())
+                for o in range(w):
+                    body[o * chunk:(o + 1) * chunk].copy_(parts[o])
+            t = t[chunk * w:]                            # < world elements left over
+            if t.numel() == 0:
+                return
+        if gpu:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
+        else:                                            # gloo has no AVG
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.div_(w)
+
     def reduce_slice(self, flat: torch.Tensor, lo: int, hi: int) -> None:
+        self._note("reduce", lo, hi)
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.AVG)
-        else:                                            # gloo has no AVG
-            dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM)
-            flat[lo:hi].div_(world())
+                self._reduce(flat[lo:hi])
+        else:
+            self._reduce(flat[lo:hi])
         self.slices.append((lo, hi))
+
+    def run_backward(self, token: Optional[int], flat: torch.Tensor, n_units: int, run_all, run_units,
+                     param_range) -> None:
+        """The sequencing every native backward goes through (EncoderRuntime.backward_impl; the 2-rank gloo
+        test drives it with a stand-in for the kernels).  run_all(): the whole backward in one native call;
+        run_units(ub, ue): units [ub, ue), after which the exchange stream has been made to wait for their
+        producers; param_range(ub, ue) -> flat slices complete after those units."""
+        if not self.claim_backward(token):
+            run_all()
+            return
+        self._note("exchange", self.epoch)
+        for ub, ue in self.unit_ranges(n_units):
+            run_units(ub, ue)
+            for lo, hi in param_range(ub, ue):
+                self.reduce_slice(flat, lo, hi)
+        self.finished_backward()
 
     def finished_backward(self) -> None:
         self.armed = False
@@ -121,6 +225,7 @@ class BucketedGradSync:
     def wait(self, flat: torch.Tensor) -> bool:
         """Compute stream waits for the exchange; False when no overlapped exchange was done."""
         if not self.pending:
+            self.armed = False                           # an armed micro-step whose backward never came
             return False
         if self.stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)

@@ -323,7 +323,7 @@ class EncoderRuntime:
         keys = saved[off:off + B * self.geom.vocab_size * 4].view(torch.int32).view(B, -1).to(torch.int64) & 0xFFFFFFFF
         return 0xFFFF - (keys & 0xFFFF)
 
-    def backward_impl(self, saved: torch.Tensor, aux, g_sparse: torch.Tensor):
+    def backward_impl(self, saved: torch.Tensor, aux, g_sparse: torch.Tensor, sync_token=None):
         ids, mask, cu, pos, rg, rl, T, B, S, groups = aux  # B = total sequences, S = longest
         dev = self._device()
         if g_sparse.shape != (B, self.geom.vocab_size):
@@ -340,24 +340,36 @@ class EncoderRuntime:
                 grads.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             ret = grads
-        sync = self.grad_sync if (self.direct_grads and self.grad_sync is not None and self.grad_sync.armed) else None
+        sync = self.grad_sync if (self.direct_grads and self.grad_sync is not None) else None
         with torch.cuda.device(dev):
             nbytes = fn("snx_model_bwd_workspace_bytes")(C.byref(self._desc), T, B, S)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             args = (C.byref(self._desc), self._param_ptrs(), self._grad_ptrs(grads), _p(self._weights()), _p(ids),
                     _p(mask), _p(cu), _p(pos), _p(rg), _p(rl), _p(saved), _p(g), _p(scratch), groups, T, B, S)
-            if sync is None:
+
+            def run_all():
                 check(fn("snx_model_backward")(*args, _stream()), "snx_model_backward")
+
+            def run_units(ub, ue):
+                # the native call makes the exchange stream wait for the launch stream and the weight-gradient stream
+                check(fn("snx_model_backward_units")(*args, ub, ue, C.c_void_p(sync.stream.cuda_stream), _stream()),
+                      "snx_model_backward_units")
+
+            if sync is None:
+                run_all()
             else:
-                # gradient exchange overlapped with the backward: after each unit range its finished slice of the
-                # flat gradient is all-reduced on the exchange stream while the next range computes
-                L = self.geom.num_hidden_layers
-                for ub, ue in sync.unit_ranges(L + 2):
-                    check(fn("snx_model_backward_units")(*args, ub, ue, C.c_void_p(sync.stream.cuda_stream), _stream()),
-                          "snx_model_backward_units")
-                    for lo, hi in self.unit_param_range(ub, ue):
-                        sync.reduce_slice(self.flat_grad, lo, hi)
-                sync.finished_backward()
+                # gradient exchange overlapped with the LAST backward of an armed micro-step (BucketedGradSync): after
+                # each unit range its finished slice of the flat gradient is reduced on the exchange stream while the
+                # next range computes; while it runs the persistent kernels leave CUs to RCCL's channel workgroups
+                reserve = sync.reserved_cus if (sync.armed and sync_token == sync.epoch and sync.outstanding == 1) else 0
+                if reserve:
+                    fn("snx_set_reserved_cus")(reserve)
+                try:
+                    sync.run_backward(sync_token, self.flat_grad, self.geom.num_hidden_layers + 2, run_all, run_units,
+                                      self.unit_param_range)
+                finally:
+                    if reserve:
+                        fn("snx_set_reserved_cus")(0)
         return ret
 
     def __call__(self, input_ids, attention_mask):
@@ -389,6 +401,8 @@ class _SpladeEncodeFn(torch.autograd.Function):
         ctx.n_in = 2 * n_pairs + 1
         sparse, tw, saved, aux = rt.forward_many_impl(pairs, save=True, lengths=lengths)
         ctx.rt, ctx.saved_arena, ctx.aux = rt, saved, aux
+        # an armed micro-step counts its saving forwards: only the backward of the last outstanding one exchanges
+        ctx.sync_token = rt.grad_sync.on_forward() if (rt.direct_grads and rt.grad_sync is not None) else None
         if rt.keep_last_ctx:
             rt.last_ctx = (saved, aux)      # parity tests: routing of the latest forward
         ctx.mark_non_differentiable(tw)
@@ -397,7 +411,7 @@ class _SpladeEncodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_sparse, _g_tw):
         rt = ctx.rt
-        grads = rt.backward_impl(ctx.saved_arena, ctx.aux, g_sparse)
+        grads = rt.backward_impl(ctx.saved_arena, ctx.aux, g_sparse, ctx.sync_token)
         ctx.saved_arena = None
         head = (None, None) + tuple(None for _ in range(ctx.n_in))
         if grads is None:

@@ -101,6 +101,78 @@ def test_native_data_parallel_collectives_reach_rccl(dev, nccl_world1, monkeypat
         assert float(d.max()) <= 2 * 2 * 1e-3 * 1.01 and float(d.mean()) < 0.02 * 1e-3, (n, float(d.max()), float(d.mean()))
 
 
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_three_backward_micro_step_exchanges_once_after_the_last_backward(dev, nccl_world1, monkeypatch, mode):
+    """SNX_FUSED_PASSES=0: query / positive / negative run as three native forwards and three native backwards per
+    micro-step (the reference's call pattern, ref:train_v33_ddp.py:339-343,364).  Every backward adds into the same
+    flat gradient, so the overlapped exchange must run inside the LAST of the three and every slice must be reduced
+    exactly once, after the last backward call that writes it (round-2 review: it ran inside the first).  Also drives
+    the reduce-scatter + all-gather form of the bucket exchange and the reserved-CU launches of the dW kernel through
+    RCCL at world size 1; parameters after the optimizer steps must agree with the fused-pass run."""
+    from oracle import splade_oracle as O
+    from snx import dist as sdist
+    from snx._lib import fn
+    from src.model.losses import SPLADELossV33
+    from src.train.config.v33 import V33Config
+    from src.train.core import ddp_trainer as T
+    from tests.test_gpu_model import _build_model, _small_cfg
+    cfg = _small_cfg()
+    params = O.perturb_params(O.init_params(cfg, seed=3), seed=4, scale=2.0, bias_mean=-0.1)
+    gen = torch.Generator().manual_seed(78)
+    batches = [O.synth_batch(4, 24, 70, cfg, gen, k=1, ragged=True) for _ in range(4)]
+    conf = V33Config()
+    conf.training.gradient_accumulation_steps = 2
+    conf.training.learning_rate = 1e-3
+    monkeypatch.setenv("SNX_DIST_FORCE", "1")
+    monkeypatch.setenv("SNX_GRAD_EXCHANGE", mode)
+    monkeypatch.setenv("SNX_PACK", "0")                     # same (padded) execution in both runs
+
+    def run(fused):
+        monkeypatch.setenv("SNX_FUSED_PASSES", "1" if fused else "0")
+        model = T.NativeDataParallel(_build_model(cfg, params, dev), n_buckets=3)
+        gs_ = model.module.runtime.grad_sync
+        assert gs_.mode == mode
+        gs_.keep_log = True
+        loss_fn = SPLADELossV33(temperature=20.0, flops_warmup_steps=4).to(dev)
+        opt = T.build_optimizer(model, conf)
+        sch = T.build_scheduler(opt, 0, 4)
+        step = 0
+        for i, b in enumerate(batches):
+            last = (i + 1) % 2 == 0
+            T.micro_step(model, loss_fn, b, step, dev, 2, last_of_window=last)
+            if last:
+                T.optimizer_step(model, opt, sch, conf)
+                step += 1
+        torch.cuda.synchronize()
+        assert fn("snx_get_reserved_cus")() == 0            # reset after every armed backward
+        return {n: p.detach().clone() for n, p in model.module.named_parameters()}, gs_, model
+
+    p_fused, g_fused, _ = run(True)
+    p_three, g_three, m = run(False)
+    total = m.module.runtime.flat_grad.numel()
+    for gs_, nfwd in ((g_fused, 1), (g_three, 3)):
+        # split the log into armed micro-steps (one epoch each)
+        epochs = sorted({e[1] for e in gs_.log if e[0] == "fwd"})
+        assert len(epochs) == 2                              # two armed micro-steps (the last of each window)
+        for ep in epochs:
+            ev = [e for e in gs_.log if (e[0] in ("fwd", "bwd", "exchange") and e[1] == ep) or e[0] == "reduce"]
+            i_ex = next(i for i, e in enumerate(gs_.log) if e[0] == "exchange" and e[1] == ep)
+            before = [e for e in gs_.log[:i_ex] if e[0] in ("fwd", "bwd") and e[1] == ep]
+            assert [e[0] for e in before] == ["fwd"] * nfwd + ["bwd"] * nfwd, before
+            assert [e[2] for e in before if e[0] == "bwd"] == [False] * (nfwd - 1) + [True]
+            reds = []
+            for e in gs_.log[i_ex + 1:]:
+                if e[0] != "reduce":
+                    break
+                reds.append((e[1], e[2]))
+            cov = sorted(reds)
+            assert cov[0][0] == 0 and cov[-1][1] == total and all(a[1] == b[0] for a, b in zip(cov, cov[1:])), cov
+            del ev
+    for n in p_fused:
+        d = (p_fused[n] - p_three[n]).abs()
+        assert float(d.max()) <= 2 * 2 * 1e-3 * 1.01 and float(d.mean()) < 0.03 * 1e-3, (n, float(d.max()), float(d.mean()))
+
+
 def test_bucket_plan_covers_every_unit(dev):
     from snx.dist import BucketedGradSync
     for nb in (1, 2, 4, 8, 22, 40):

@@ -308,7 +308,77 @@ def _dist_worker(rank, world, port, ret):
     ok4 = ok4 and cov[0][0] == 0 and cov[-1][1] == total and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
     ok4 = ok4 and gs.wait(flat) and not gs.wait(flat)
     ok4 = ok4 and torch.allclose(flat, torch.arange(total, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
-    ret[rank] = (bool(ok1), bool(ok2), bool(ok3), bool(ok4))
+    # (4) a micro-step of THREE backward calls (the reference's call pattern, ref:train_v33_ddp.py:339-343 -> one
+    # reduction; here SNX_FUSED_PASSES=0 or a custom loop): only the backward that returns the LAST outstanding
+    # forward token may exchange, after it has written.  The stand-in for the kernels adds rank- and call-dependent
+    # gradients unit range by unit range (the tied embedding matrix gets a share in unit 0 and the rest in the last
+    # unit, like the real backward), through the same BucketedGradSync.run_backward the runtime uses.
+    E = (0, sizes[0])
+    base = torch.arange(total, dtype=torch.float32) + 1.0
+
+    def contribution(k):
+        return base * float((rank + 1) * (k + 1))
+
+    def drive(gs, flat, k, token):
+        c = contribution(k)
+
+        def run_all():
+            flat.add_(c)
+
+        def run_units(ub, ue):
+            if ub == 0:
+                flat[E[0]:E[1]].add_(0.25 * c[E[0]:E[1]])
+            for lo, hi in rt.unit_param_range(ub, ue):
+                if lo == 0:                                  # the slice that starts with the embedding matrix
+                    flat[E[0]:E[1]].add_(0.75 * c[E[0]:E[1]])
+                    lo = E[1]
+                flat[lo:hi].add_(c[lo:hi])
+        gs.run_backward(token, flat, L + 2, run_all, run_units, rt.unit_param_range)
+
+    ok5 = True
+    mean_rank = sum(range(1, world + 1)) / world
+    for mode in ("allreduce", "rs_ag"):
+        gs = BucketedGradSync(torch.device("cpu"), 3, mode=mode)
+        gs.keep_log = True
+        flat = torch.zeros(total)
+        for last in (False, True):                           # accumulation window of two micro-steps
+            gs.arm(last)
+            toks = [gs.on_forward() for _ in range(3)]       # query, positive, negative forwards
+            for k in (2, 1, 0):                              # autograd runs the backwards in reverse order
+                drive(gs, flat, k, toks[k])
+        ok5 = ok5 and gs.pending and gs.wait(flat)
+        want = base * (2 * (1 + 2 + 3) * mean_rank)
+        ok5 = ok5 and torch.allclose(flat, want, rtol=1e-6)
+        ev = [e for e in gs.log if e[0] in ("bwd", "reduce", "exchange")]
+        last_bwd = max(i for i, e in enumerate(ev) if e[0] == "bwd")
+        first_red = min(i for i, e in enumerate(ev) if e[0] == "reduce")
+        ok5 = ok5 and ev[last_bwd][2] is True and first_red > last_bwd
+        ok5 = ok5 and sum(1 for e in ev if e[0] == "bwd" and e[2]) == 1 and sum(1 for e in ev if e[0] == "exchange") == 1
+        cov = sorted((e[1], e[2]) for e in ev if e[0] == "reduce")
+        ok5 = ok5 and cov[0][0] == 0 and cov[-1][1] == total and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
+    # (5) misuse is loud or safe: a graph built BEFORE arm() disarms the overlap (the caller's sync_gradients() then
+    # reduces the whole buffer); a backward between a finished exchange and wait() raises
+    gs = BucketedGradSync(torch.device("cpu"), 3)
+    flat = torch.zeros(total)
+    stale = gs.on_forward()                                  # not armed: no token
+    gs.arm(True)
+    drive(gs, flat, 0, stale)
+    ok6 = stale is None and not gs.armed and not gs.pending and not gs.wait(flat)
+    ok6 = ok6 and torch.equal(flat, contribution(0))         # nothing was reduced
+    gs.arm(True)
+    drive(gs, flat, 0, gs.on_forward())
+    try:
+        drive(gs, flat, 0, None)
+        ok6 = False
+    except RuntimeError:
+        pass
+    try:
+        gs.arm(True)
+        ok6 = False
+    except RuntimeError:
+        pass
+    ok6 = ok6 and gs.wait(flat)
+    ret[rank] = (bool(ok1), bool(ok2), bool(ok3), bool(ok4), bool(ok5), bool(ok6))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -319,4 +389,4 @@ def test_world_size_2_collectives_gloo():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_dist_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
-    assert dict(ret) == {0: (True, True, True, True), 1: (True, True, True, True)}
+    assert dict(ret) == {0: (True,) * 6, 1: (True,) * 6}
