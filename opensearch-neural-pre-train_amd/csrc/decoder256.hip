@@ -37,10 +37,15 @@ namespace {
 constexpr int HS = 32;               // k per half-step
 constexpr int SUBT = 128 * 64;       // LDS sub-tile of Hd: 128 rows x 64 B
 constexpr int PART = 2 * SUBT;       // Hd slice: 256 rows x 32 k
-constexpr int TV = 192;              // vocabulary columns of a tile; 192, not 256: 64 AGPRs stay free, which hipcc needs
+#ifdef SNX_DEC256_OVERSUBSCRIBE     // compile-only variant for the build guard's self-test (snx/asmcheck.py, tests/
+constexpr int NJ = 4;                // test_build_guard.py): all 256 AGPRs as accumulators -> hipcc spills fragment registers
+#else                                // behind the asm LDS reads; the launcher refuses to run it
+constexpr int NJ = 3;
+#endif
+// NJ: 32-column accumulator tiles per wave along the vocabulary: wave tile 128 x 96
+constexpr int TV = 64 * NJ;          // vocabulary columns of a tile; 192, not 256: 64 AGPRs stay free, which hipcc needs
                                      // as spill space (with all 256 taken it spills to scratch inside the K loop)
-constexpr int NJ = 3;                // 32-column accumulator tiles per wave along the vocabulary: wave tile 128 x 96
-constexpr int SUBW = 96 * 64;        // LDS sub-tile of W_E: 96 rows x 64 B
+constexpr int SUBW = 32 * NJ * 64;   // LDS sub-tile of W_E: 96 rows x 64 B
 constexpr int SLOT = PART + 2 * SUBW;   // Hd slice + W slice = 28 KiB
 constexpr int RING = 5;
 constexpr int NWG = 256;
@@ -482,6 +487,7 @@ int snx_launch_decoder256(const void* Hd, const void* W, const float* bias, cons
                           int32_t T, int32_t nseq, int32_t V, int32_t K, hipStream_t st) {
   if ((K % 64) || T <= 0 || nseq <= 0 || V <= 0 || (long)T * K * 2 >= (1L << 32) || (long)V * K * 2 >= (1L << 32))
     return SNX_E_SHAPE;
+  if (NJ != 3) return SNX_E_SHAPE;                    // the DMA / read schedule of the K loop is written for NJ = 3
   char* base = (char*)scratch + ((rowpart_bytes + 255) & ~(size_t)255);
   int32_t* list = (int32_t*)base;
   int32_t* nvalid = list + T;

@@ -13,6 +13,8 @@ import glob
 import os
 import subprocess
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # `snx` importable when run as a script
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -65,6 +67,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"build failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    # Guard (snx/asmcheck.py): the persistent kernels read LDS through volatile asm; a build in which hipcc copies or
+    # spills one of those destination registers before the source's s_waitcnt returns intermittently wrong rows.
+    # Every (re)compiled guarded source is re-assembled with the same flags and scanned; a failing object is removed
+    # so that no library can be linked from it.  Zero scratch is required too, except in the documented diagnostics
+    # build (-DSNX_GEMM_TRACE keeps an 8-byte time stamp in scratch), which is held to the scan alone.
+    from snx import asmcheck
+    extra = os.environ.get("SNX_EXTRA_HIPCC_FLAGS", "").split()
+    rebuilt = {os.path.basename(j[-3]) for j in jobs}
+    for b in sorted(rebuilt & set(asmcheck.GUARDED)):
+        try:
+            asmcheck.check_file(b, extra, allow_scratch="-DSNX_GEMM_TRACE" in extra)
+        except asmcheck.AsmGuardError:
+            o = os.path.join(OBJ, b[:-4] + ".o")
+            if os.path.exists(o):
+                os.remove(o)
+            raise
     if force or jobs or _newer(objs, LIB):
         tl = _torch_lib_dir()
         if tl:

@@ -1,0 +1,115 @@
+"""Build-time guard for the asm LDS reads of the persistent kernels (snx/asmcheck.py; round-2 review, Weak #1).
+
+The kernels read their MFMA fragments through ``asm volatile("ds_read_...")``; hipcc cannot see that the
+destination registers are invalid until the source's ``s_waitcnt lgkmcnt``.  A build whose register allocator copies
+or spills such a register inside that window is wrong at run time, intermittently.  ``snx/build.py`` therefore
+re-assembles every guarded source and scans it; these tests pin the scanner and run it on the tree (hipcc
+cross-compiles gfx950 without a GPU)."""
+import os
+
+import pytest
+
+from snx import asmcheck as A
+
+needs_hipcc = pytest.mark.skipif(not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")), reason="no hipcc")
+
+
+def test_scanner_on_hand_written_streams():
+    ok = ["ds_read_b128 v[12:15], v0", "v_mfma_f32_32x32x16_bf16 a[0:15], v[4:7], v[8:11], a[0:15]",
+          "s_waitcnt lgkmcnt(0)", "v_accvgpr_write_b32 a200, v12"]
+    assert A.scan_kernel(ok) == []
+    spill = ["ds_read_b128 v[12:15], v0", "v_accvgpr_write_b32 a200, v13", "s_waitcnt lgkmcnt(0)"]
+    assert len(A.scan_kernel(spill)) == 1
+    scratch = ["ds_read_b64_tr_b16 v[20:21], v3", "scratch_store_dwordx2 off, v[20:21], off offset:8", "s_waitcnt lgkmcnt(0)"]
+    assert len(A.scan_kernel(scratch)) == 1
+    # a vmcnt-only wait retires nothing
+    vm = ["ds_read_b128 v[12:15], v0", "s_waitcnt vmcnt(0)", "v_mov_b32 v1, v12", "s_waitcnt lgkmcnt(0)"]
+    assert len(A.scan_kernel(vm)) == 1
+    # counted wait: LDS reads return in order, all but the N newest are retired ...
+    cnt = ["ds_read_b128 v[12:15], v0", "ds_read_b128 v[16:19], v0", "s_waitcnt lgkmcnt(1)", "v_mov_b32 v1, v12"]
+    assert A.scan_kernel(cnt) == []
+    assert len(A.scan_kernel(cnt[:3] + ["v_mov_b32 v1, v16"])) == 1
+    # ... unless a scalar load (same counter, out of order) is outstanding
+    sm = ["ds_read_b128 v[12:15], v0", "s_load_dwordx2 s[0:1], s[4:5], 0x0", "ds_read_b128 v[16:19], v0",
+          "s_waitcnt lgkmcnt(1)", "v_mov_b32 v1, v12"]
+    assert len(A.scan_kernel(sm)) == 1
+    # overwriting a pending destination is as bad as reading it
+    waw = ["ds_read_b128 v[12:15], v0", "v_mov_b32 v14, 0", "s_waitcnt lgkmcnt(0)"]
+    assert len(A.scan_kernel(waw)) == 1
+    # the read's own address register may be reused at once
+    addr = ["ds_read_b128 v[12:15], v0", "v_add_u32 v0, 64, v0", "s_waitcnt lgkmcnt(0)"]
+    assert A.scan_kernel(addr) == []
+
+
+def test_kernel_splitter_and_scratch_rule():
+    asm = """
+\t.text
+_Z3foov:
+\tds_read_b128 v[0:3], v4
+\tv_mov_b32 v9, v1
+\ts_waitcnt lgkmcnt(0)
+\ts_endpgm
+\t.section\t.rodata
+\t.amdhsa_kernel _Z3foov
+\t\t.amdhsa_private_segment_fixed_size 0
+\t.end_amdhsa_kernel
+\t.text
+_Z3barv:
+\tds_read_b128 v[0:3], v4
+\ts_waitcnt lgkmcnt(0)
+\tscratch_store_dword off, v1, off
+\ts_endpgm
+\t.section\t.rodata
+\t.amdhsa_kernel _Z3barv
+\t\t.amdhsa_private_segment_fixed_size 16
+\t.end_amdhsa_kernel
+"""
+    ks = A.kernels_of(asm)
+    assert set(ks) >= {"_Z3foov", "_Z3barv"} and len(ks["_Z3foov"]) == 4
+    with pytest.raises(A.AsmGuardError, match="touch the destination"):
+        A.check_asm(asm, ["foo"])
+    with pytest.raises(A.AsmGuardError, match="scratch"):
+        A.check_asm(asm, ["bar"])
+    assert A.check_asm(asm, ["bar"], allow_scratch=True)["_Z3barv"]["scratch"] == 16
+    with pytest.raises(A.AsmGuardError, match="no kernel matching"):
+        A.check_asm(asm, ["nope"])
+
+
+@needs_hipcc
+def test_tree_passes_with_product_flags():
+    rep = A.check_all()
+    names = " ".join(rep)
+    assert "gemm_tn256_kernel" in names and "decoder256_kernel" in names
+    assert all(v["scratch"] == 0 and v["reads"] > 0 for v in rep.values()), rep
+
+
+@needs_hipcc
+def test_tree_passes_as_diagnostics_build():
+    # README: SNX_EXTRA_HIPCC_FLAGS=-DSNX_GEMM_TRACE (in-kernel stamps; one 8-byte stamp lives in scratch)
+    rep = A.check_all(["-DSNX_GEMM_TRACE"], allow_scratch=True)
+    assert len(rep) >= 3
+
+
+@needs_hipcc
+def test_guard_fails_on_an_over_subscribed_variant():
+    # all 256 AGPRs as accumulators (256-column decoder tile): hipcc spills -- the build must refuse it
+    with pytest.raises(A.AsmGuardError):
+        A.check_file("decoder256.hip", ["-DSNX_DEC256_OVERSUBSCRIBE"])
+
+
+@needs_hipcc
+def test_build_removes_the_object_of_a_failing_kernel(tmp_path, monkeypatch):
+    """snx.build with flags that over-subscribe a guarded kernel: raises and leaves no object behind to link."""
+    from snx import build as B
+    obj = tmp_path / "_obj"
+    obj.mkdir()
+    monkeypatch.setattr(B, "OBJ", str(obj))
+    monkeypatch.setattr(B, "LIB", str(tmp_path / "libsnx_test.so"))
+    monkeypatch.setenv("SNX_EXTRA_HIPCC_FLAGS", "-DSNX_DEC256_OVERSUBSCRIBE")
+    real_glob = B.glob.glob
+    # only the guarded source needs compiling for this check
+    monkeypatch.setattr(B.glob, "glob", lambda pat: [f for f in real_glob(pat) if not pat.endswith("*.hip")
+                                                     or f.endswith("decoder256.hip")])
+    with pytest.raises(A.AsmGuardError):
+        B.build()
+    assert not (obj / "decoder256.o").exists() and not (tmp_path / "libsnx_test.so").exists()
