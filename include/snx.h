@@ -154,6 +154,12 @@ int snx_gemm_nt_resid(const void* A, const void* B, const float* Hin, float* Hou
 /* ... Wqkv fused with apply_rotary_pos_emb (hf:271-280): columns < rope_cols (q and k) rotated. */
 int snx_gemm_nt_rope(const void* A, const void* B, void* C, const float* rope_tab, const int32_t* pos,
                      int32_t rope_cols, int32_t M, int32_t N, int32_t K, hipStream_t stream);
+/* The same with the (cos, sin) row of every token resolved beforehand: rope_rows [M][32][2] fp32 = rope_tab[pos[row]]
+ * (snx_rope_rows, once per forward pass and theta; NULL = resolve through pos inside the kernel).  Lets the 256x256
+ * kernel's write-back read a row's 256 bytes without the dependent position load.  Same results. */
+int snx_rope_rows(const float* cos_sin_tab, const int32_t* pos, float* rope_rows, int32_t T, hipStream_t stream);
+int snx_gemm_nt_rope_rows(const void* A, const void* B, void* C, const float* rope_tab, const int32_t* pos,
+                          const float* rope_rows, int32_t rope_cols, int32_t M, int32_t N, int32_t K, hipStream_t stream);
 /* ... Wi fused with GeGLU (hf:90-91).  B = Wi rows in the interleaved order of snx_cast_geglu_interleave;
  * U [M,N] = Wi output in that column order (saved for backward), Y [M,N/2] = gelu(a) * g. */
 int snx_gemm_nt_geglu_fwd(const void* A, const void* B_interleaved, void* U, void* Y, int32_t M, int32_t N,
@@ -161,6 +167,12 @@ int snx_gemm_nt_geglu_fwd(const void* A, const void* B_interleaved, void* U, voi
 /* ... dX of mlp.Wo fused with the GeGLU backward: dy = A B^T [M,N=I]; dU [M,2N] (interleaved). */
 int snx_gemm_nt_geglu_bwd(const void* A, const void* B, const void* U, void* dU, int32_t M, int32_t N, int32_t K,
                           hipStream_t stream);
+/* Dispatch of the five entry points above: from `min_m` rows on (default 8,192; env SNX_NT256_MIN_M) and N % 64 == 0
+ * they run the 256x256 persistent kernel (csrc/gemm_nt256.hip), otherwise the 128x128 kernel (csrc/gemm.hip); same
+ * results bit for bit (both sum k in the same order).  on = 0 (env SNX_NT256=0) keeps everything on the 128x128
+ * kernel, 1 = the default shape policy (wide outputs with the plain / RoPE / GeGLU-forward epilogues), 2 = every
+ * eligible shape (tests, A/B); min_m <= 0 leaves the threshold unchanged.  Process-wide host state. */
+int snx_nt256_configure(int32_t on, int32_t min_m);
 /* fp32 Wi [2I,C] -> bf16 interleaved copy out [2I,C] and/or its transpose out_t [C,2I]: every 64-row
  * group = [a rows 32q..32q+31 | g rows 32q..32q+31] (so a and its gate meet in one lane of the GEMM). */
 int snx_cast_geglu_interleave(const float* in, void* out, void* out_t, int32_t I, int32_t C, hipStream_t stream);

@@ -406,6 +406,26 @@ __global__ void rope_kernel(bf16_t* __restrict__ qkv, const f32x2* __restrict__ 
   *(bf16x8*)(base + 32) = ohi;
 }
 
+// rows[t] = tab[pos[t]]: the (cos, sin) row of every token, resolved once per forward pass for all layers of one
+// theta (256 B per token; one wave per 4 tokens, 16 B per lane)
+__global__ void rope_rows_kernel(const f32x4* __restrict__ tab, const int32_t* __restrict__ pos, f32x4* __restrict__ rows,
+                                 int T) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // 16-byte piece: token i >> 4, piece i & 15
+  if (i >= (long)T * 16) return;
+  const int t = (int)(i >> 4);
+  rows[i] = tab[(long)pos[t] * 16 + (i & 15)];
+}
+
+extern "C" int snx_rope_rows(const float* cos_sin_tab, const int32_t* pos, float* rows, int32_t T, hipStream_t st) {
+  if (!cos_sin_tab || !pos || !rows) return SNX_E_ARG;
+  if (T <= 0) return SNX_E_SHAPE;
+  const long n = (long)T * 16;
+  hipLaunchKernelGGL(rope_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const f32x4*)cos_sin_tab, pos,
+                     (f32x4*)rows, T);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
 extern "C" int snx_rope_inplace(void* qkv, const float* cos_sin_tab, const int32_t* pos, int32_t T, int32_t heads,
                                 int32_t inverse, hipStream_t st) {
   if (!qkv || !cos_sin_tab || !pos || T <= 0 || heads <= 0) return SNX_E_ARG;

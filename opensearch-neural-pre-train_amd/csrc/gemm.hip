@@ -19,21 +19,9 @@
 // 4-stage ring (571), persistent workgroups with cross-tile prefetch (neutral), stream-K for dW.
 // Two independent 4-wave workgroups per CU with one barrier per 64-deep K-step win.
 #include "gemm_core.h"
+#include "gemm_epi.h"
 #include "gemm_tn.h"
 #include "snx.h"
-
-enum { EPI_STORE_BF16 = 0, EPI_RESID_F32 = 1, EPI_ROPE = 2, EPI_GEGLU_FWD = 3, EPI_GEGLU_BWD = 4 };
-
-struct EpiArgs {
-  bf16_t* C;                 // STORE / ROPE: [M,N];  GEGLU_FWD: u [M,N] interleaved;  GEGLU_BWD: du [M,2N] interleaved
-  const float* Hin;          // RESID
-  float* Hout;               // RESID
-  const f32x2* rope_tab;     // ROPE: [max_pos][32] (cos, sin)
-  const int32_t* pos;        // ROPE: [M] position of each row
-  int rope_cols;             // ROPE: columns < rope_cols (= 2*hidden) are rotated
-  bf16_t* Y;                 // GEGLU_FWD: y [M, N/2]
-  const bf16_t* U;           // GEGLU_BWD: u [M, 2N] interleaved
-};
 
 #ifdef SNX_GEMM_TRACE
 // Diagnostics build only (-DSNX_GEMM_TRACE, tools/gpu_gemm_trace.py): wave 0 of every workgroup records the
@@ -47,36 +35,6 @@ extern "C" int snx_gemm_trace_set(void* buf) {
 #else
 #define TRACE_T(k)
 #endif
-
-__device__ __forceinline__ bf16x4 pack4(const f32x4 v) { return (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; }
-
-// ---- coalesced epilogue -----------------------------------------------------------------------
-// In the (transposed) accumulator layout the 16 lanes li = 0..15 of a store instruction are 16
-// different ROWS, so a direct store is 64 separate 8-byte transactions per instruction and the
-// texture addresser, not HBM, sets the epilogue time (measured on the 256x256 kernel: 786 TFLOP/s
-// with such stores, 1047 without, no change when all stores hit one L2-resident region).  Each
-// wave therefore bounces its 64x64 bf16 result through a PRIVATE 8 KiB of the (finished) operand
-// LDS and writes it back row-major, 16 B per lane, 8 lanes per 128-byte line.
-// Staging image: 64 rows x 128 B; 16-B chunk c of row r sits at chunk c ^ (r & 7) and its two
-// 8-B halves are swapped when bit 3 of r is set -- ds_write_b64 from the accumulator layout and
-// ds_read_b128 in the row-major layout are both bank-conflict free.
-__device__ __forceinline__ void stg_put(char* w, int row, int col, bf16x4 v) {        // col % 4 == 0
-  *(bf16x4*)(w + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + ((((col >> 2) ^ (row >> 3)) & 1) << 3)) = v;
-}
-template <bool SWAP>
-__device__ __forceinline__ bf16x8 stg_get(const char* w, int row, int chunk) {
-  const bf16x8 v = *(const bf16x8*)(w + row * 128 + (((chunk ^ row) & 7) << 4));
-  if (!SWAP) return v;
-  return (bf16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
-}
-// second staging image for a 64 x 32 result (GeGLU's y): rows of 64 B
-__device__ __forceinline__ void stg32_put(char* w, int row, int col, bf16x4 v) {
-  *(bf16x4*)(w + row * 64 + ((((col >> 3) ^ (row >> 1)) & 3) << 4) + ((((col >> 2) ^ (row >> 3)) & 1) << 3)) = v;
-}
-__device__ __forceinline__ bf16x8 stg32_get(const char* w, int row, int chunk) {
-  const bf16x8 v = *(const bf16x8*)(w + row * 64 + (((chunk ^ (row >> 1)) & 3) << 4));
-  return ((row >> 3) & 1) ? (bf16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]} : v;
-}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool MID>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_kernel(
@@ -226,8 +184,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_kernel(
         for (int r = 0; r < 4; ++r) {
           const float c = pre[i * 2 + j][r >> 1][(r & 1) * 2], sn = pre[i * 2 + j][r >> 1][(r & 1) * 2 + 1];
           const float x1 = rbf(acc[i][j][r]), x2 = rbf(acc[i][j + 2][r]);   // Linear output is bf16
-          lo[r] = x1 * c - x2 * sn;
-          hi[r] = x2 * c + x1 * sn;
+          lo[r] = __builtin_fmaf(x1, c, -(x2 * sn));      // (explicit contraction: the same in gemm_nt256.hip)
+          hi[r] = __builtin_fmaf(x2, c, x1 * sn);
         }
         stg_put(w, lrow, j * 16 + g4, pack4(lo));
         stg_put(w, lrow, (j + 2) * 16 + g4, pack4(hi));
@@ -297,6 +255,12 @@ static int launch_nt(const void* A, const void* B, int M, int N, int K, const Ep
   if ((EPI == EPI_ROPE || EPI == EPI_GEGLU_FWD) && (N % 64) != 0) return SNX_E_SHAPE;
   if (EPI == EPI_GEGLU_BWD && (N % 32) != 0) return SNX_E_SHAPE;
   if (!A || !B) return SNX_E_ARG;
+  {
+    // many rows: the 256x256 persistent form (gemm_nt256.hip); SNX_E_SHAPE = not taken (small M, odd N, epilogue
+    // not built there yet)
+    const int rc = snx_launch_nt256(EPI, A, B, M, N, K, e, st);
+    if (rc != SNX_E_SHAPE) return rc;
+  }
   constexpr int BM = 128, BN = 128;
   using Core = GemmCore<BM, BN, 2, 2>;
   const int tm = cdiv(M, BM), tn = cdiv(N, BN);
@@ -357,6 +321,17 @@ extern "C" int snx_gemm_nt_rope(const void* A, const void* B, void* C, const flo
   if (rope_cols < 0 || rope_cols > N || (rope_cols % 64) != 0) return SNX_E_SHAPE;
   EpiArgs e{};
   e.C = (bf16_t*)C; e.rope_tab = (const f32x2*)rope_tab; e.pos = pos; e.rope_cols = rope_cols;
+  return launch_nt<EPI_ROPE>(A, B, M, N, K, e, stream);
+}
+
+extern "C" int snx_gemm_nt_rope_rows(const void* A, const void* B, void* C, const float* rope_tab, const int32_t* pos,
+                                     const float* rope_rows, int32_t rope_cols, int32_t M, int32_t N, int32_t K,
+                                     hipStream_t stream) {
+  if (!C || !rope_tab || !pos) return SNX_E_ARG;
+  if (rope_cols < 0 || rope_cols > N || (rope_cols % 64) != 0) return SNX_E_SHAPE;
+  EpiArgs e{};
+  e.C = (bf16_t*)C; e.rope_tab = (const f32x2*)rope_tab; e.pos = pos; e.rope_cols = rope_cols;
+  e.rope_rows = (const f32x2*)rope_rows;
   return launch_nt<EPI_ROPE>(A, B, M, N, K, e, stream);
 }
 

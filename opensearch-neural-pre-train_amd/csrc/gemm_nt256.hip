@@ -1,0 +1,594 @@
+// Encoder NT GEMMs, 256x256 persistent "ping-pong" form:  C[M,N] = A[M,K] * B[N,K]^T, bf16 operands, fp32 MFMA
+// accumulation, the five fused epilogues of gemm.hip (replaces the cuBLAS calls behind nn.Linear under autocast(bf16),
+// transformers modeling_modernbert.py:90-91,271,300,490 via ref:src/model/splade_modern.py:69-73).
+//
+// Why a second form.  The 128x128 kernel (two independent 4-wave workgroups per CU) moves 65 FLOP per byte from L2
+// into LDS and its two waves per SIMD are unsynchronised: measured 60 % MFMA issue inside the K loop, 0.30 of the
+// bf16 peak over the encoder's shapes.  Here ONE 8-wave workgroup owns the CU (256x256x64 tile: 131 FLOP per byte),
+// and the two waves of every SIMD (wave w and w + 4: the upper and lower half of the tile's rows) run the same
+// program ONE BARRIER APART, so that while one multiplies the other reads LDS and issues LDS-DMA:
+//
+//   slot:        s         s+1        s+2        s+3 ...
+//   waves 0-3:   LOAD p    MFMA p     LOAD p+1   MFMA p+1
+//   waves 4-7:   MFMA p-1  LOAD p     MFMA p     LOAD p+1          (every slot ends in one s_barrier)
+//
+// A K-tile (64 deep) is four phases, one 64x32 quadrant of the wave's 128x64 accumulator each (16 MFMAs of
+// v_mfma_f32_16x16x32_bf16); the operands of K-tile t+1 arrive by LDS-DMA in four 16 KiB chunks ordered by the phase
+// that first needs them, one chunk issued per phase, and every LOAD segment ends with a COUNTED s_waitcnt vmcnt(4):
+// everything but the two newest chunks has landed, two chunks stay in flight across the barrier -- and across
+// K-tile and output-tile boundaries: the workgroup is persistent and the pipeline never drains.  RAW: a chunk is
+// read one barrier after every issuing wave's covering wait; WAR: a chunk's LDS region was last read >= 3 slots
+// before its refill is issued.  LDS: 2 stages x (256x64 A + 256x64 B) bf16 = 128 KiB, rows of 128 B, 16-B chunks
+// XOR-swizzled with (row & 7) on the DMA source and on the read (conflict-free ds_read_b128), + 4 KiB per wave of
+// private staging for the write-back = 160 KiB.
+//
+// Work split without a tail and without inter-workgroup traffic.  The output is cut into UNITS of 64 rows x 256
+// columns, linearised as (tile position in the XCD-aware column-group order of gemm_core.h) x (4 units per tile);
+// workgroup L of 256 takes units [U L / 256, U (L + 1) / 256).  Cutting that range at tile boundaries gives a few
+// whole 256-row tiles plus at most two SHORT tiles of 64, 128 or 192 rows.  A short tile of 64 u rows keeps the
+// LDS image and the schedule of a whole one: wave group g's rows [32 u g, 32 u (g + 1)) of the tile land in its
+// usual LDS rows (the DMA source rows are remapped, rows past 32 u re-read a valid row), the MFMAs of row tiles
+// that do not exist are skipped (phases of 16, 8 or 0 MFMAs), the write-back stops after u passes.  36,864 token
+// rows x 2,304 columns: 20.25 units per workgroup -> 21 at most (96 % balance; whole tiles only: 6 rounds for 5.06).
+//
+// Epilogue.  The last barrier of a tile is taken BEFORE the write-back by the leading wave group and AFTER it by the
+// trailing one, so both groups write back in the same slot (exposed once, not twice).  Per pass of 32 rows a wave
+// packs its accumulators to bf16 into its private 4 KiB (swizzled image of gemm_epi.h) and writes them back
+// row-major, 16 B per lane = full 128-byte lines.  The stores stay in flight into the next tile: its first two
+// LOAD segments wait with vmcnt(4 + stores) (the vm queue retires in order).
+#include "gemm_core.h"
+#include "gemm_epi.h"
+#include "snx.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;   // 64 KiB
+constexpr int BOUNCE = 4096;                          // per wave: 32 rows x 64 columns bf16
+constexpr int LDS_TOTAL = 2 * STAGE + 8 * BOUNCE;     // 160 KiB
+constexpr int NWG = 256;
+
+struct Work {
+  TileOrder order;                   // tile position -> (row panel, column tile), gemm_core.h
+  long units;                        // 4 * tm * tn
+  int dbg;                           // diagnostics: 1 = no write-back, 2 = every tile reads operand tile (0, 0),
+                                     // 4 = write-back without its global stores, 8 = stores drain at once (no vmcnt slack),
+                                     // 16 = no deep request at tile boundaries
+};
+
+struct Tile { int m0, n0, u; };      // first row, first column, 64-row units (0: no tile)
+
+// tile rows covered by DMA chunk c (A: c = 0 -> LDS rows [0,64) + [128,192), c = 3 -> [64,128) + [192,256);
+// B: c = 1 -> n-half 0 of the four wave columns, c = 2 -> n-half 1); ci = 0..15 eight-row groups
+__device__ __forceinline__ int chunk_row(int c, int ci) {
+  if (c == 0) return (ci < 8 ? 0 : 128) + (ci & 7) * 8;
+  if (c == 3) return (ci < 8 ? 64 : 192) + (ci & 7) * 8;
+  return (ci >> 2) * 64 + (c == 2 ? 32 : 0) + (ci & 3) * 8;
+}
+
+// per-lane byte offsets of this wave's two DMA instructions per chunk, for the tile being prefetched (k offset apart)
+struct Off { unsigned c[4][2]; };
+
+__device__ __forceinline__ bf16x8 frag256(const char* tile, int row, int chunk) {
+  return *(const bf16x8*)(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define BARRIER()                          \
+  do {                                     \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+
+template <int N>
+struct IC { static constexpr int value = N; };
+
+// store instructions of one wave's write-back of a WHOLE tile (they stay in flight into the next tile): 16 plain,
+// 32 with the residual / GeGLU-backward / rotated-RoPE epilogues, 24 with the GeGLU forward
+
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                         int M, int N, int K, Work wk, EpiArgs e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;                  // wave group (row half) and column of the 2x4 grid
+  const int nk = K / BK;
+  const int li = lane & 15, g = lane >> 4;
+  const int L = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous logical id
+  // this workgroup's units
+  long x = wk.units * L / gridDim.x;
+  const long xe = wk.units * (L + 1) / gridDim.x;
+
+  auto next_tile = [&]() __attribute__((always_inline)) {                                  // tile starting at unit x (u = 0: none); advances x
+    Tile t;
+    t.m0 = 0; t.n0 = 0; t.u = 0;
+    if (x >= xe) return t;
+    const int q0 = (int)(x & 3);
+    const long left = xe - x;
+    t.u = 4 - q0 < left ? 4 - q0 : (int)left;
+    int pm, pn;
+    tile_of(wk.order, (int)(x >> 2), pm, pn);
+    t.m0 = pm * BM + q0 * 64;
+    t.n0 = pn * BN;
+    x += t.u;
+    return t;
+  };
+
+  // DMA source offsets of a tile: LDS row r of the A image (wave group r >> 7, row lr = r & 127 inside it) holds
+  // tile row 32 u (r >> 7) + lr for lr < 32 u and re-reads row 0 of the tile otherwise; rows past M re-read row M - 1
+  auto offsets = [&](const Tile& t, Off& o) __attribute__((always_inline)) {
+    int lane = threadIdx.x & 63;                            // opaque copy: recompute the lane arithmetic per call (once per
+    asm volatile("" : "+v"(lane));                          // tile) instead of keeping a dozen hoisted registers live
+    const int u32 = 32 * t.u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = chunk_row(c, i * 8 + wave) + (lane >> 3);
+        const int ch = (lane & 7) ^ (r & 7);
+        int gr;
+        if (c == 0 || c == 3) {
+          const int lr = r & 127;
+          gr = ((wk.dbg & 2) ? 0 : t.m0) + (lr < u32 ? (r >> 7) * u32 + lr : 0);
+          gr = gr < M ? gr : M - 1;
+        } else {
+          gr = ((wk.dbg & 2) ? 0 : t.n0) + r;
+          gr = gr < N ? gr : N - 1;
+        }
+        o.c[c][i] = ((unsigned)gr * (unsigned)K + (unsigned)(ch * 8)) * 2u;
+      }
+  };
+  auto dma = [&](auto cc, const Off& o, int kbytes, char* stage) __attribute__((always_inline)) {
+    constexpr int C = decltype(cc)::value;
+    constexpr bool isA = (C == 0 || C == 3);
+    const char* base = (const char*)(isA ? A : B) + kbytes;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      char* dst = stage + (isA ? 0 : A_BYTES) + chunk_row(C, i * 8 + wave) * 128;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(base + o.c[C][i]), LDS_PTR(dst), 16, 0, 0);
+    }
+  };
+
+  Tile cur = next_tile();
+  if (cur.u == 0) return;
+  Off off;
+  offsets(cur, off);
+  // prologue: all four chunks of the first K-tile
+  dma(IC<0>(), off, 0, smem);
+  dma(IC<1>(), off, 0, smem);
+  dma(IC<2>(), off, 0, smem);
+  dma(IC<3>(), off, 0, smem);
+  WAIT_VM(0);
+  BARRIER();
+  if (wm == 1) BARRIER();                                   // stagger the lower-row wave group by one slot
+
+  char* bounce = smem + 2 * STAGE + wave * BOUNCE;
+  int stage_par = 0;
+  int pend = 0;                                             // stores of the previous tile's write-back still in the vm queue
+  bool deep = false;                                        // this tile's K-tile 1 was requested during the previous write-back
+  f32x4 acc[8][4];
+
+  // ---- one K-tile: four phases; N01 / N23 = row tiles (of 16 rows) of the wave in its first / second 64 rows ----
+  // issue: request chunk p of the next K-tile in phase p (false: K-tile 0 of a tile whose K-tile 1 was requested during
+  // the previous write-back).  hold: bit p set = the wait of phase p leaves the previous write-back's stores in
+  // flight (vmcnt(4 + stores) instead of vmcnt(4)).  Two scalar branches per phase and no more: a LOAD segment runs
+  // beside the partner group's 16 MFMAs = 256 cycles; with five branches per phase every launch was 15 % slower.
+  auto ktile = [&](auto n01, auto n23, const char* st, char* nst, bool issue, int hold, int kbytes) __attribute__((always_inline)) {
+    constexpr int N01 = decltype(n01)::value, N23 = decltype(n23)::value;
+    auto wait_landed = [&](int ph) __attribute__((always_inline)) {
+      if ((hold >> ph) & 1) {
+        if (EPI == EPI_GEGLU_FWD) WAIT_VM(28);
+        else if (EPI == EPI_RESID_F32 || EPI == EPI_GEGLU_BWD) WAIT_VM(36);
+        else if (EPI == EPI_ROPE && pend == 32) WAIT_VM(36);
+        else WAIT_VM(20);
+      } else {
+        WAIT_VM(4);
+      }
+    };
+    const char* ta = st + (wm * 128) * 128;                 // this wave's 128 A rows
+    const char* tb = st + A_BYTES + (wn * 64) * 128;        // this wave's 64 B rows (output columns)
+    bf16x8 a[2][4], b0[2][2], b1[2][2];
+    // ---------------- phase 0: quadrant (rows 0..63, cols 0..31) ----------------
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < N01; ++i) a[kk][i] = frag256(ta, i * 16 + li, kk * 4 + g);
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn) b0[kk][jn] = frag256(tb, jn * 16 + li, kk * 4 + g);
+    }
+    if (issue) dma(IC<0>(), off, kbytes, nst);
+    wait_landed(0);
+    BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < N01; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[kk][jn], a[kk][i], acc[i][jn], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    BARRIER();
+    // ---------------- phase 1: quadrant (rows 0..63, cols 32..63) ----------------
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn) b1[kk][jn] = frag256(tb, 32 + jn * 16 + li, kk * 4 + g);
+    if (issue) dma(IC<1>(), off, kbytes, nst);
+    wait_landed(1);
+    BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < N01; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+          acc[i][2 + jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[kk][jn], a[kk][i], acc[i][2 + jn], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    BARRIER();
+    // ---------------- phase 2: quadrant (rows 64..127, cols 32..63) ----------------
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < N23; ++i) a[kk][i] = frag256(ta, 64 + i * 16 + li, kk * 4 + g);
+    if (issue) dma(IC<2>(), off, kbytes, nst);
+    wait_landed(2);
+    BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < N23; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+          acc[4 + i][2 + jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[kk][jn], a[kk][i], acc[4 + i][2 + jn], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    BARRIER();
+    // ---------------- phase 3: quadrant (rows 64..127, cols 0..31) ----------------
+    if (issue) dma(IC<3>(), off, kbytes, nst);
+    wait_landed(3);
+    BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < N23; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+          acc[4 + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[kk][jn], a[kk][i], acc[4 + i][jn], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    // (the trailing barrier of the K-tile is the caller's: the last one of an output tile frames the write-back)
+  };
+
+  // diagnostics (SNX_NT256_DBG bit 4): the write-back without its global stores (results kept alive in registers)
+#define NT256_STORE(T, ptr, val)                           \
+  do {                                                     \
+    const T v__ = (val);                                   \
+    if (wk.dbg & 4) asm volatile("" ::"v"(v__));           \
+    else *(T*)(ptr) = v__;                                 \
+  } while (0)
+  // ---- write-back of the wave's 32 u x 64 result (transposed accumulators: lane owns 4 consecutive columns) ----
+  //   acc[i][jn][r] = C[row0 + 16 i + li][col0 + 16 jn + 4 g + r]
+  // Passes of 32 rows (16 for the GeGLU forward, whose second image y shares the 4 KiB): the operands a pass reads
+  // from memory (residual rows, saved u, RoPE table rows) are requested one pass ahead.
+  auto epilogue = [&](const Tile& t, auto deep_request) __attribute__((always_inline)) {
+    const int row0 = t.m0 + wm * 32 * t.u;                  // first row of this wave
+    const int col0 = t.n0 + wn * 64;
+    if (col0 >= N || (wk.dbg & 1)) {                        // wave-uniform: a column span past the matrix (N % 256 != 0)
+      deep_request();
+      return;
+    }
+    // opaque copy of the lane id: none of the lane arithmetic below may be hoisted in front of the K loops, where
+    // every register is taken (hipcc hoisted it and spilled 7 registers to scratch)
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, g = lane >> 4;
+    const int rr = lane >> 3, rc = lane & 7;                // row-major role: rows rr + 8 k of a pass, 8 columns from 8 rc
+    const int col = col0 + rc * 8;
+    if (EPI == EPI_GEGLU_FWD) {
+      deep_request();
+      // passes of 16 rows: image u (16 x 128 B) + image y (16 x 64 B); same software pipeline as below
+      char* img_y = bounce + 2048;
+      const int ycol = (col0 >> 1) + (lane & 3) * 8;
+      auto put_g = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+          const bf16x4 a4 = pack4(acc[p][jn]), g4 = pack4(acc[p][jn + 2]);
+          stg_put(bounce, li, jn * 16 + g * 4, a4);
+          stg_put(bounce, li, (jn + 2) * 16 + g * 4, g4);
+          bf16x4 y4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y4[r] = f2bf(rbf(gelu_f(bf2f(a4[r]))) * bf2f(g4[r]));
+          stg32_put(img_y, li, jn * 16 + g * 4, y4);
+        }
+      };
+      put_g(0);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        if (p >= 2 * t.u) break;
+        const bf16x8 v0 = stg_get<false>(bounce, rr, rc), v1 = stg_get<true>(bounce, rr + 8, rc);
+        const bf16x8 vy = stg32_get(img_y, lane >> 2, lane & 3);
+        if (p + 1 < 8 && p + 1 < 2 * t.u) put_g(p + 1);
+        const int r0 = row0 + 16 * p + rr, ry = row0 + 16 * p + (lane >> 2);
+        if (r0 < M) NT256_STORE(bf16x8, e.C + (long)r0 * N + col, v0);
+        if (r0 + 8 < M) NT256_STORE(bf16x8, e.C + (long)(r0 + 8) * N + col, v1);
+        if (ry < M) NT256_STORE(bf16x8, e.Y + (long)ry * (N >> 1) + ycol, vy);
+      }
+      return;
+    }
+    constexpr bool PRE = (EPI == EPI_RESID_F32 || EPI == EPI_GEGLU_BWD || EPI == EPI_ROPE);
+    const bool rotate = EPI == EPI_ROPE && col0 < e.rope_cols;      // wave-uniform: a head of q or k
+    f32x4 pre[2][PRE ? 8 : 1];
+    // RoPE runs in the ROW-MAJOR layout of the read-back (lane = row rr + 8 k, columns 8 rc ..): lane (q = rc & 3,
+    // h = rc >> 2) rotates the four pairs d = 8 q + 4 h + 0..3 of its row, (d, d + 32), read as two 8-byte pieces of
+    // the staging image; its (cos, sin) are 32 contiguous bytes of the table row, 256 B per row over the 8 lanes
+    // (in the accumulator layout the same values were 16 rows x 64 B per load instruction: +33 us per launch).
+    // the positions of a pass's rows are loaded TWO passes ahead, its table rows one pass ahead
+    int prow[4][4];
+    const bool by_row = EPI == EPI_ROPE && e.rope_rows != nullptr;   // (cos, sin) rows resolved per token beforehand
+    auto request_pos = [&](int p) __attribute__((always_inline)) {
+      if (EPI == EPI_ROPE && rotate && !by_row) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int row = row0 + 32 * p + rr + 8 * k;
+          prow[p][k] = e.pos[row < M ? row : M - 1];
+        }
+      }
+    };
+    request_pos(0);
+    if (t.u > 1) request_pos(1);
+    auto request = [&](int p) __attribute__((always_inline)) {
+      if (EPI == EPI_ROPE) {
+        if (rotate) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            int row = row0 + 32 * p + rr + 8 * k;
+            row = row < M ? row : M - 1;
+            const f32x2* trow = by_row ? e.rope_rows + (long)row * 32 : e.rope_tab + (long)prow[p][k] * 32;
+            const f32x4* cs = (const f32x4*)(trow + (rc & 3) * 8 + (rc >> 2) * 4);
+            pre[p & 1][2 * k] = cs[0];                       // (cos, sin) of pairs d, d + 1
+            pre[p & 1][2 * k + 1] = cs[1];                   // d + 2, d + 3
+          }
+        }
+      } else if (PRE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int row = row0 + 32 * p + rr + 8 * k;
+          row = row < M ? row : M - 1;
+          if (EPI == EPI_RESID_F32) {
+            const float* h = e.Hin + (long)row * N + col;
+            pre[p & 1][2 * k] = *(const f32x4*)h;
+            pre[p & 1][2 * k + 1] = *(const f32x4*)(h + 4);
+          } else {                                          // dy columns [col, col+8) <-> a at u[64 q + 8 s], g at +32
+            const bf16_t* uu = e.U + (long)row * (2 * N) + 64 * (col >> 5) + (col & 31);
+            pre[p & 1][2 * k] = *(const f32x4*)uu;           // 8 bf16 of a
+            pre[p & 1][2 * k + 1] = *(const f32x4*)(uu + 32);   // 8 bf16 of g
+          }
+        }
+      }
+    };
+    // accumulators of pass p -> staging image (bf16)
+    auto put = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+          stg_put(bounce, ii * 16 + li, jn * 16 + g * 4, pack4(acc[2 * p + ii][jn]));
+    };
+    if (PRE) request(0);
+    deep_request();
+    put(0);
+    // Software pipeline over the ONE image: the row-major reads of pass p are issued, then the image is refilled
+    // with pass p + 1 (LDS executes a wave's instructions in order: the refill cannot overtake the reads), then the
+    // reads are consumed -- their latency runs under the packing and the writes of the next pass.
+    const int d = (rc & 3) * 8 + (rc >> 2) * 4;             // RoPE: this lane's four rotation pairs
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (p >= t.u) break;                                  // wave-uniform: a short tile has u passes
+      if (p + 2 < 4 && p + 2 < t.u) request_pos(p + 2);
+      if (PRE && p + 1 < 4 && p + 1 < t.u) request(p + 1);
+      bf16x8 v[4];
+      bf16x4 x1[4], x2[4];
+      if (EPI == EPI_ROPE && rotate) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                       // the Linear's output is bf16: rotate what was rounded
+          x1[k] = stg_get4(bounce, rr + 8 * k, d);
+          x2[k] = stg_get4(bounce, rr + 8 * k, 32 + d);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v[k] = (k & 1) ? stg_get<true>(bounce, rr + 8 * k, rc) : stg_get<false>(bounce, rr + 8 * k, rc);
+      }
+      if (p + 1 < 4 && p + 1 < t.u) put(p + 1);
+      if (EPI == EPI_ROPE && rotate) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int row = row0 + 32 * p + rr + 8 * k;
+          const f32x4 q0 = pre[p & 1][2 * k], q1 = pre[p & 1][2 * k + 1];
+          f32x4 lo, hi;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float c = (r < 2 ? q0 : q1)[(r & 1) * 2], sn = (r < 2 ? q0 : q1)[(r & 1) * 2 + 1];
+            const float a1 = bf2f(x1[k][r]), a2 = bf2f(x2[k][r]);
+            lo[r] = __builtin_fmaf(a1, c, -(a2 * sn));
+            hi[r] = __builtin_fmaf(a2, c, a1 * sn);
+          }
+          if (row >= M) continue;
+          bf16_t* o = e.C + (long)row * N + col0 + d;
+          NT256_STORE(bf16x4, o, pack4(lo));
+          NT256_STORE(bf16x4, o + 32, pack4(hi));
+        }
+        continue;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = row0 + 32 * p + rr + 8 * k;
+        if (row >= M) continue;
+        if (EPI == EPI_RESID_F32) {
+          const f32x4 h0 = pre[p & 1][2 * k], h1 = pre[p & 1][2 * k + 1];
+          float* o = e.Hout + (long)row * N + col;
+          NT256_STORE(f32x4, o, ((f32x4){h0[0] + bf2f(v[k][0]), h0[1] + bf2f(v[k][1]), h0[2] + bf2f(v[k][2]), h0[3] + bf2f(v[k][3])}));
+          NT256_STORE(f32x4, o + 4, ((f32x4){h1[0] + bf2f(v[k][4]), h1[1] + bf2f(v[k][5]), h1[2] + bf2f(v[k][6]), h1[3] + bf2f(v[k][7])}));
+        } else if (EPI == EPI_GEGLU_BWD) {                  // v = dy (bf16); du = GeGLU'(u, dy)
+          const bf16x8 a8 = __builtin_bit_cast(bf16x8, pre[p & 1][2 * k]), g8 = __builtin_bit_cast(bf16x8, pre[p & 1][2 * k + 1]);
+          bf16x8 da, dg;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float af = bf2f(a8[r]), gf = bf2f(g8[r]), df = bf2f(v[k][r]);
+            dg[r] = f2bf(df * rbf(gelu_f(af)));
+            da[r] = f2bf(rbf(df * gf) * gelu_grad_f(af));
+          }
+          bf16_t* o = e.C + (long)row * (2 * N) + 64 * (col >> 5) + (col & 31);
+          NT256_STORE(bf16x8, o, da);
+          NT256_STORE(bf16x8, o + 32, dg);
+        } else {
+          NT256_STORE(bf16x8, e.C + (long)row * N + col, v[k]);
+        }
+      }
+    }
+  };
+
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) acc[i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const Tile nxt = next_tile();
+    const int u = cur.u;
+    // (one K loop per tile height: with the four bodies inside one loop hipcc spilled 300 registers)
+    // The previous write-back's stores may stay in flight through K-tile 0 -- and, when K-tile 1 was requested ahead
+    // of them (deep), through the first two phases of K-tile 1: the vm queue retires in order.
+    auto kloop = [&](auto n01, auto n23) __attribute__((always_inline)) {
+      for (int kt = 0; kt < nk; ++kt, stage_par ^= 1) {
+        const char* st = smem + stage_par * STAGE;
+        char* nst = smem + (stage_par ^ 1) * STAGE;
+        // where the next K-tile comes from (next k of this output tile, or k = 0 of the next one).  The very last
+        // K-tile of the workgroup re-requests its own chunks into the free stage (nobody reads them): the waits
+        // then need no third form; the requests are drained before the workgroup ends.
+        const bool more_k = kt + 1 < nk;
+        if (!more_k && nxt.u > 0) offsets(nxt, off);        // the prefetch stream moves on to the next tile
+        const int kbytes = more_k ? (kt + 1) * (BK * 2) : 0;
+        const int soft = kt == 0 ? (deep ? 15 : 3) : (kt == 1 && deep) ? 3 : 0;
+        ktile(n01, n23, st, nst, !(deep && kt == 0), pend ? soft : 0, kbytes);
+        if (more_k) BARRIER();
+      }
+    };
+    if (u == 4) kloop(IC<4>(), IC<4>());
+    else if (u == 3) kloop(IC<4>(), IC<2>());
+    else if (u == 2) kloop(IC<4>(), IC<0>());
+    else kloop(IC<2>(), IC<0>());
+    // the leading group writes back after the tile's last barrier, the trailing group before it: same slot
+    if (wm == 0) BARRIER();
+    // K-tile 1 of the next tile is requested HERE, in front of the write-back's stores: its stage is the one just
+    // consumed (last read >= 3 slots ago).  K-tile 0 of the next tile then requests nothing and its waits -- like
+    // those of the first half of K-tile 1 -- leave the stores in flight: a whole K-tile for the 128 KiB burst to
+    // drain behind the MFMAs instead of in front of them.
+    // (behind the first operand loads of the write-back itself: the queue returns in order)
+    const bool deep_next = nxt.u > 0 && nk >= 2 && !(wk.dbg & 16);
+    auto deep_request = [&]() __attribute__((always_inline)) {
+      if (deep_next) {
+        char* s1 = smem + (stage_par ^ 1) * STAGE;
+        dma(IC<0>(), off, BK * 2, s1);
+        dma(IC<1>(), off, BK * 2, s1);
+        dma(IC<2>(), off, BK * 2, s1);
+        dma(IC<3>(), off, BK * 2, s1);
+      }
+    };
+    epilogue(cur, deep_request);
+    if (wm != 0) BARRIER();
+    deep = deep_next;
+    // a whole tile inside the matrix: this wave has just issued a known number of stores
+    pend = 0;
+    if ((u == 4) && !(wk.dbg & 5) && (cur.n0 + wn * 64 < N) && (cur.m0 + wm * 128 + 127 < M)) {
+      pend = 16;
+      if (EPI == EPI_RESID_F32 || EPI == EPI_GEGLU_BWD) pend = 32;
+      if (EPI == EPI_GEGLU_FWD) pend = 24;
+      if (EPI == EPI_ROPE && cur.n0 + wn * 64 < e.rope_cols) pend = 32;
+      if (wk.dbg & 8) pend = 0;
+    }
+    cur = nxt;
+    if (cur.u == 0) break;
+  }
+  if (wm == 0) BARRIER();                                   // balance the stagger barrier
+  WAIT_VM(0);                                               // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+template <int EPI>
+static int launch(const void* A, const void* B, int M, int N, int K, const EpiArgs& e, hipStream_t st) {
+  const int tm = cdiv(M, BM), tn = cdiv(N, BN);
+  // column-group width of the tile order: an XCD's share of B (cg tiles of 256 x K bf16) should stay in its 4 MiB L2
+  // beside the streaming A panels and outputs; re-reading the A panels ceil(tn / cg) times is the price
+  static const int cg_env = getenv("SNX_NT256_CG") ? atoi(getenv("SNX_NT256_CG")) : -1;
+  static const int dbg = getenv("SNX_NT256_DBG") ? atoi(getenv("SNX_NT256_DBG")) : 0;
+  int cg = tn;
+  if (cg_env > 0) cg = cg_env < tn ? cg_env : tn;
+  else if (cg_env < 0) {
+    const double a_bytes = 2.0 * M * K, b_bytes = 2.0 * N * K, cap = 2.2e6;
+    double best = -1;
+    for (int parts = 1; parts <= 4; ++parts) {
+      const int c = cdiv(tn, parts);
+      const double bsub = 2.0 * c * BN * K;
+      const double cost = a_bytes * cdiv(tn, c) + 8.0 * b_bytes * (bsub <= cap ? 1.0 : 4.0);
+      if (best < 0 || cost < best) { best = cost; cg = c; }
+    }
+  }
+  Work wk;
+  wk.order = TileOrder{tm, tn, cdiv(tm, 8), cg};
+  wk.units = 4L * tm * tn;
+  wk.dbg = dbg;
+  static bool attr[64] = {};
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return SNX_E_ARG;
+  auto kern = gemm_nt256_kernel<EPI>;
+  static bool done[64] = {};
+  if (!done[devid]) {
+    hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (err != hipSuccess) return (int)err;
+    done[devid] = true;
+  }
+  (void)attr;
+  hipLaunchKernelGGL(kern, dim3(NWG), dim3(512), LDS_TOTAL, st, (const bf16_t*)A, (const bf16_t*)B, M, N, K, wk, e);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+// Shapes this form takes: enough rows to give every workgroup work, N % 64 == 0 (16-byte row-major write-back in
+// whole 64-column wave spans), K % 64 == 0, operand byte offsets within 32 bits.
+static int g_nt256_on = -1, g_nt256_min_m = -1;
+// A/B and test switch (also env SNX_NT256 / SNX_NT256_MIN_M, read once): on = 0 keeps every shape on the 128x128 kernel
+extern "C" int snx_nt256_configure(int32_t on, int32_t min_m) {
+  g_nt256_on = on;                                     // 0 = off, 1 = default shape policy, 2 = every eligible shape
+  if (min_m > 0) g_nt256_min_m = min_m;
+  return SNX_OK;
+}
+
+int snx_launch_nt256(int epi, const void* A, const void* B, int M, int N, int K, const EpiArgs& e, hipStream_t st) {
+  if (g_nt256_on < 0) g_nt256_on = getenv("SNX_NT256") ? atoi(getenv("SNX_NT256")) != 0 : 1;
+  if (g_nt256_min_m < 0) g_nt256_min_m = getenv("SNX_NT256_MIN_M") ? atoi(getenv("SNX_NT256_MIN_M")) : 8192;
+  const int on = g_nt256_on, min_m = g_nt256_min_m;
+  // Which shapes come here by default (measured at 36,864 rows against the 128x128 kernel, tools/gpu_nt256.py):
+  // wide outputs (>= 6 column tiles: ~20 units per workgroup, short tiles are a small share) with the plain, RoPE
+  // and GeGLU-forward epilogues.  Three column tiles (N = 768) leave 6.75 units per workgroup, i.e. one whole tile
+  // and one or two short ones that cost most of a whole tile's latency-bound K loop, and the two epilogues that
+  // stream a second operand (residual, GeGLU backward) gain nothing from the exposed write-back.
+  // SNX_NT256_FORCE=<bitmask over EPI>: take every eligible shape of those epilogues (A/B runs).
+  static const int force = getenv("SNX_NT256_FORCE") ? atoi(getenv("SNX_NT256_FORCE")) : 0;
+  const bool dflt = (epi == EPI_STORE_BF16 || epi == EPI_ROPE || epi == EPI_GEGLU_FWD) && N >= 6 * BN;
+  if (on != 2 && !dflt && !((force >> epi) & 1)) return SNX_E_SHAPE;   // on = 2 (snx_nt256_configure): take all
+  if (!on || M < min_m || (N % 64) || (K % 64) || K < 64) return SNX_E_SHAPE;
+  if ((long)M * K * 2 >= (1L << 32) || (long)N * K * 2 >= (1L << 32)) return SNX_E_SHAPE;
+  switch (epi) {
+    case EPI_STORE_BF16: return launch<EPI_STORE_BF16>(A, B, M, N, K, e, st);
+    case EPI_RESID_F32: return launch<EPI_RESID_F32>(A, B, M, N, K, e, st);
+    case EPI_ROPE: return launch<EPI_ROPE>(A, B, M, N, K, e, st);
+    case EPI_GEGLU_FWD: return launch<EPI_GEGLU_FWD>(A, B, M, N, K, e, st);
+    case EPI_GEGLU_BWD: return launch<EPI_GEGLU_BWD>(A, B, M, N, K, e, st);
+    default: return SNX_E_SHAPE;
+  }
+}

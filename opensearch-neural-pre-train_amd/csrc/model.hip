@@ -75,6 +75,7 @@ struct SavedPlan {
   size_t xf, dd, hd;             // final-norm out, head.dense out (pre-GELU), head out: bf16 [T,H]
   size_t keys;                   // u32 [nseq,V]
   size_t rowpart;                // forward-only scratch of the SPLADE head
+  size_t rope_rows[2];           // fp32 [T,32,2]: every token's (cos, sin) row for theta_global / theta_local
   size_t total;
 };
 
@@ -103,6 +104,8 @@ bool plan_saved(const snx_model_desc* d, long T, long nseq, bool save, SavedPlan
   s.xf = take(T * H * 2); s.dd = take(T * H * 2); s.hd = take(T * H * 2);
   s.keys = take(nseq * V * 4);
   s.rowpart = take(snx_splade_head_scratch_bytes((int)T, (int)V));
+  s.rope_rows[0] = take(T * 256);
+  s.rope_rows[1] = take(T * 256);
   s.total = off;
   return true;
 }
@@ -323,12 +326,16 @@ extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* par
 
   const double TH = (double)T * H;
   { PROF(PC_EMBED, TH * 10); RC(snx_embed_ln_fwd(ids, F(p.tok_emb()), F(p.emb_norm()), hbuf(0), sv + s.x_attn[0], T, H, d->ln_eps, st)); }
+  // positions -> (cos, sin) rows once per pass and theta: the 22 Wqkv write-backs then read them without the dependent load
+  { PROF(PC_ROPE, 2.0 * T * 512);
+    RC(snx_rope_rows(rope_global, pos, (float*)(sv + s.rope_rows[0]), T, st));
+    RC(snx_rope_rows(rope_local, pos, (float*)(sv + s.rope_rows[1]), T, st)); }
   for (int l = 0; l < L; ++l) {
     const bool global = (l % d->global_every) == 0;
     if (l > 0) { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l), F(p.attn_norm(l)), sv + s.x_attn[l], T, H, d->ln_eps, st)); }
     { PROF(PC_GEMM_NT, 2.0 * T * 3 * H * H);      // Wqkv + RoPE fused
-      RC(snx_gemm_nt_rope(sv + s.x_attn[l], wc + c.wqkv[l], sv + s.qkv[l], global ? rope_global : rope_local, pos,
-                          2 * H, T, 3 * H, H, st)); }
+      RC(snx_gemm_nt_rope_rows(sv + s.x_attn[l], wc + c.wqkv[l], sv + s.qkv[l], global ? rope_global : rope_local, pos,
+                               (const float*)(sv + s.rope_rows[global ? 0 : 1]), 2 * H, T, 3 * H, H, st)); }
     { PROF(PC_ATTN_FWD, 4.0 * H * attn_pairs(groups, nseq, max_seqlen, global ? -1 : d->window));
       RC(snx_attn_fwd_ex(sv + s.qkv[l], cu_seqlens, mask, sv + s.attn[l], (float*)(sv + s.lse[l]), groups, T, nseq,
                          max_seqlen, d->heads, d->head_dim, global ? -1 : d->window, st)); }

@@ -39,10 +39,13 @@ SIGNATURES = {
     "snx_attn_fwd_ex": (I32, [P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_attn_bwd_ex": (I32, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_gemm_nt_rope": (I32, [P, P, P, P, P, I32, I32, I32, I32, P]),
+    "snx_rope_rows": (I32, [P, P, P, I32, P]),
+    "snx_gemm_nt_rope_rows": (I32, [P, P, P, P, P, P, I32, I32, I32, I32, P]),
     "snx_gemm_nt_geglu_fwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "snx_gemm_nt_geglu_bwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "snx_gemm_tn_accum_interleaved": (I32, [P, P, P, I32, I32, I32, P]),
     "snx_gemm_tn_accum_group": (I32, [P, I32, I32, P]),
+    "snx_nt256_configure": (I32, [I32, I32]),
     "snx_set_reserved_cus": (I32, [I32]),
     "snx_get_reserved_cus": (I32, []),
     "snx_cast_geglu_interleave": (I32, [P, P, P, I32, I32, P]),

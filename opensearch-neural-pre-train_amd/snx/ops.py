@@ -103,6 +103,29 @@ def gemm_nt_rope(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor, pos: tor
     return c
 
 
+def rope_rows(table: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """[T, 32, 2] fp32 = table[pos]: every token's (cos, sin) row, resolved once per pass and theta."""
+    _chk(table, torch.float32, "table"); _chk(pos, torch.int32, "pos")
+    T = pos.shape[0]
+    rows = torch.empty((T, 32, 2), dtype=torch.float32, device=pos.device)
+    check(fn("snx_rope_rows")(_p(table), _p(pos), _p(rows), T, _stream()), "snx_rope_rows")
+    return rows
+
+
+def gemm_nt_rope_rows(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, rows: torch.Tensor,
+                      rope_cols: int):
+    """gemm_nt_rope with the per-token (cos, sin) rows of ``rope_rows`` handed in (same results)."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    M, K = a.shape; N = b.shape[0]
+    _chk(table, torch.float32, "table"); _chk(pos, torch.int32, "pos", (M,)); _chk(rows, torch.float32, "rows", (M, 32, 2))
+    if b.shape[1] != K or K % 64 or N % 64:
+        raise ValueError("gemm_nt_rope_rows: bad shapes")
+    c = torch.empty((M, N), dtype=BF16, device=a.device)
+    check(fn("snx_gemm_nt_rope_rows")(_p(a), _p(b), _p(c), _p(table), _p(pos), _p(rows), rope_cols, M, N, K, _stream()),
+          "snx_gemm_nt_rope_rows")
+    return c
+
+
 def cast_geglu_interleave(wi: torch.Tensor):
     """fp32 Wi [2I, C] -> (bf16 interleaved [2I, C], bf16 interleaved transposed [C, 2I])."""
     _chk(wi, torch.float32, "wi")
