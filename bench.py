@@ -76,8 +76,19 @@ def cpu_baseline(seconds_budget: float = 30.0):
     """The oracle (CPU restatement of the reference step, fp32, torch CPU threads = host cores given
     to this process) on a bounded sample: B=4 triplets per micro-step, q64/d256 full length."""
     from oracle import splade_oracle as O
-    cores = min(16, os.cpu_count() or 1)      # the GPU box gives one GPU's job a 16-core share
+    # every core this process may run on (the GPU box gives one GPU's job a share of the host); the host's own
+    # logical / physical core counts are recorded beside it
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, avail)
     torch.set_num_threads(cores)
+    try:
+        import psutil
+        host = {"logical": psutil.cpu_count(logical=True), "physical": psutil.cpu_count(logical=False)}
+    except Exception:
+        host = {"logical": os.cpu_count(), "physical": None}
     cfg = O.EncoderConfig()
     params = O.init_params(cfg, seed=42)
     st = O.TrainState(params)
@@ -96,18 +107,19 @@ def cpu_baseline(seconds_budget: float = 30.0):
         if n >= 3 and (time.time() - t_start > seconds_budget or n >= 6):
             break
     timed = times[1:] if len(times) > 1 else times
-    return {"value": 4.0 * len(timed) / sum(timed), "unit": "triplets/s", "cores": cores, "kind": "port",
+    return {"value": 4.0 * len(timed) / sum(timed), "unit": "triplets/s", "cores": cores, "host_cores": host, "kind": "port",
             "sample": f"{len(timed)} timed micro-steps (after 1 warm-up) of 4 triplets q64/d256, oracle fp32 incl. "
                       "clip+AdamW every step"}
 
 
-# kernel names (as rocprofv3 reports them) behind each profiler class, for the PMC traffic lookup
+# kernel names (as tools/pmc_traffic.py keys them) behind each profiler class, for the PMC traffic lookup
 PMC_KERNELS = {
     "gemm_nt_bf16": ["gemm_nt_kernel<128, 128, 2, 2, 0", "gemm_nt_kernel<128, 128, 2, 2, 2",
-                     "gemm_nt_kernel<128, 128, 2, 2, 3", "gemm_nt_kernel<128, 128, 2, 2, 4"],
-    "gemm_nt_resid": ["gemm_nt_kernel<128, 128, 2, 2, 1"],
-    "gemm_tn_accum": ["gemm_tn_kernel"],
-    "decoder_splade_fwd": ["decoder_splade_kernel"],
+                     "gemm_nt_kernel<128, 128, 2, 2, 3", "gemm_nt_kernel<128, 128, 2, 2, 4",
+                     "gemm_nt256_kernel<0>", "gemm_nt256_kernel<2>", "gemm_nt256_kernel<3>", "gemm_nt256_kernel<4>"],
+    "gemm_nt_resid": ["gemm_nt_kernel<128, 128, 2, 2, 1", "gemm_nt256_kernel<1>"],
+    "gemm_tn_accum": ["gemm_tn256_kernel", "gemm_tn_kernel"],
+    "decoder_splade_fwd": ["decoder256_kernel", "decoder_splade_kernel"],
     "attn_fwd": ["attn_fwd_unit_kernel", "attn_fwd_kernel"],
     "attn_bwd": ["attn_bwd_dq_unit_kernel", "attn_bwd_dkv_unit_kernel", "attn_bwd_dq_kernel", "attn_bwd_dk"],
 }
@@ -125,7 +137,7 @@ def kernel_source_hash() -> str:
     return h.hexdigest()
 
 
-PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def pmc_traffic(cls: str):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile set (run on the GPU box through gpurun; summaries are copied into profiles/ afterwards):
 #   bench JSON (config 2 and config 5), rocprofv3 kernel stats of the same command, PMC fabric traffic (two passes).
-R=${1:-r02}
+R=${1:-r03}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/prof_$R
@@ -14,6 +14,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o f -- python3 bench.
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o w -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $O/pmc_write.log 2>&1 || exit 1
 F=$(find $O/pmc_fetch -name "f_results.db" | head -1); W=$(find $O/pmc_write -name "w_results.db" | head -1)
 python3 tools/pmc_traffic.py "$F" "$W" $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
+# shader-engine counters (MFMA utilisation, where the waves' cycles go): one pass, the program directly behind `--`
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_sq -o s -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $O/pmc_sq.log 2>&1 || exit 1
+S=$(find $O/pmc_sq -name "s_results.db" | head -1)
+python3 tools/pmc_sq.py "$S" $O/sq_counters.json > $O/sq_counters.txt 2>&1
 find $O -name "*_kernel_stats.csv" | head; ls $O
 # the sqlite traces are large: keep only the summaries
 find $O -name "*.db" -delete
