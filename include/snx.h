@@ -115,6 +115,27 @@ int snx_model_backward_units(const snx_model_desc* d, const void* const* params 
                              int32_t T, int32_t nseq, int32_t max_seqlen, int32_t unit_begin, int32_t unit_end,
                              hipStream_t notify, hipStream_t stream);
 
+/* ---- fp32 execution (csrc/f32_path.hip): what the reference computes OUTSIDE torch.autocast -- a bare
+ * SPLADEModernBERT.forward (ref:src/model/splade_modern.py:50-88), its inference encoder (ref:benchmark/encoders.py:
+ * 309-345) and the fp32 leg of the tolerance protocol.  Same contract as the entry points above with fp32 weights
+ * (`params` themselves: no weight cache), fp32 activations and contraction, no bf16 cast point; any hidden size,
+ * even head_dim <= 64, any intermediate size (the tiny parity configuration runs here).  rope_* tables are
+ * [max_pos][head_dim / 2][2].  The precision path, not the throughput path. */
+size_t snx_model_workspace_bytes_f32(const snx_model_desc* d, int32_t T, int32_t nseq, int32_t save_for_bwd);
+size_t snx_model_bwd_workspace_bytes_f32(const snx_model_desc* d, int32_t T);
+int snx_model_forward_f32(const snx_model_desc* d, const void* const* params /*[host]*/, const int64_t* ids,
+                          const int64_t* mask, const int32_t* cu_seqlens, const int32_t* pos, const float* rope_global,
+                          const float* rope_local, void* saved, float* sparse, float* token_weights, int32_t T,
+                          int32_t nseq, int32_t flags, hipStream_t stream);
+int snx_model_backward_f32(const snx_model_desc* d, const void* const* params /*[host]*/, void* const* grads /*[host]*/,
+                           const int64_t* ids, const int64_t* mask, const int32_t* cu_seqlens, const int32_t* pos,
+                           const float* rope_global, const float* rope_local, const void* saved, const float* g_sparse,
+                           void* scratch, int32_t T, int32_t nseq, hipStream_t stream);
+/* fp32 GEMM on v_mfma_f32_32x32x2_f32 with strided operands: C[m,n] (+)= (R[m,n]) + sum_k A[m a_row + k a_k] B[n b_row + k b_k]
+ * (nn.Linear in fp32: forward, dX and dW are the same kernel with different strides). */
+int snx_gemm_f32(const float* A, int64_t a_row, int64_t a_k, const float* B, int64_t b_row, int64_t b_k, float* C, int64_t ldc,
+                 const float* R, int64_t ldr, int32_t M, int32_t N, int32_t K, int32_t accumulate, hipStream_t stream);
+
 /* ---- inference post-processing (ref:benchmark/encoders.py:309-345 NeuralSparseEncoderV33._encode_batch) ---- */
 /* Per row of rep [B,V] fp32: entries with rep > 0 and allowed[v] != 0 survive.  k > 0 and more than k survivors:
  * the k largest, weight descending, ties lowest id first (out_sorted[b] = 1); otherwise all survivors in id

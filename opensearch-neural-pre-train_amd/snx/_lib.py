@@ -66,6 +66,11 @@ SIGNATURES = {
     "snx_model_backward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P]),
     "snx_model_backward_units": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P]),
     "snx_sparse_topk": (I32, [P, P, P, P, P, P, I32, I32, I32, I32, P]),
+    "snx_model_workspace_bytes_f32": (SZ, [P, I32, I32, I32]),
+    "snx_model_bwd_workspace_bytes_f32": (SZ, [P, I32]),
+    "snx_model_forward_f32": (I32, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P]),
+    "snx_model_backward_f32": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, P]),
+    "snx_gemm_f32": (I32, [P, I64, I64, P, I64, I64, P, I64, P, I64, I32, I32, I32, I32, P]),
     "snx_param_count": (I32, [P]),
     "snx_adamw_scratch_bytes": (SZ, []),
     "snx_adamw_clip_step": (I32, [P, P, P, P, I64, P, I64, I64, I64, P, P, P]),

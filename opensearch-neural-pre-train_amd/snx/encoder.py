@@ -10,7 +10,7 @@ import logging
 import os
 from collections import OrderedDict
 from dataclasses import dataclass
-from typing import Callable, Dict, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple  # noqa: F401
 
 import torch
 
@@ -50,25 +50,39 @@ class EncoderGeometry:
                          self.num_attention_heads, hd, self.global_attn_every_n_layers, self.local_attention // 2,
                          self.pad_token_id, 0, self.norm_eps, 0.0)
 
-    def check_supported(self):
+    def bf16_unsupported_reason(self) -> Optional[str]:
+        """None when the bf16 kernels' tilings take this geometry, else why not."""
         hd = self.hidden_size // self.num_attention_heads
         if hd != 64 or self.hidden_size % 256 or self.hidden_size > 1024 or self.intermediate_size % 64:
-            raise ValueError("snx kernels need head_dim == 64, hidden % 256 == 0 (<= 1024), intermediate % 64 == 0; "
-                             f"got hidden={self.hidden_size}, heads={self.num_attention_heads}, "
-                             f"intermediate={self.intermediate_size}")
+            return ("the bf16 kernels need head_dim == 64, hidden % 256 == 0 (<= 1024), intermediate % 64 == 0; "
+                    f"got hidden={self.hidden_size}, heads={self.num_attention_heads}, intermediate={self.intermediate_size}")
         if (2 * self.intermediate_size) % 128 or self.intermediate_size % 128 or self.hidden_size % 128:
-            raise ValueError("weight-gradient GEMM needs hidden, intermediate multiples of 128")
+            return "the weight-gradient GEMM needs hidden, intermediate multiples of 128"
+        return None
+
+    def check_supported(self):
+        r = self.bf16_unsupported_reason()
+        if r:
+            raise ValueError("snx: " + r)
+
+    def check_f32_supported(self):
+        hd = self.hidden_size // self.num_attention_heads
+        if hd * self.num_attention_heads != self.hidden_size or hd > 64 or hd % 2:
+            raise ValueError("snx fp32 path: head_dim must be even and <= 64")
+
+    def n_params(self) -> int:
+        return 2 + (5 + 6 * (self.num_hidden_layers - 1)) + 4
 
 
 class EncoderRuntime:
     """Binds parameters (canonical order, see include/snx.h) to the native forward/backward."""
 
     def __init__(self, geom: EncoderGeometry, params: Sequence[torch.nn.Parameter]):
-        geom.check_supported()
+        geom.check_f32_supported()             # the bf16 kernels' tighter limits are checked when that path is taken
         self.geom = geom
         self.params = list(params)
         self._desc = geom.desc()
-        n = fn("snx_param_count")(C.byref(self._desc))
+        n = geom.n_params()
         if n != len(self.params):
             raise ValueError(f"expected {n} parameter tensors in canonical order, got {len(self.params)}")
         self._ptr_key = None
@@ -86,7 +100,6 @@ class EncoderRuntime:
         self.last_ctx = None
         # bucketed gradient exchange overlapped with the backward (snx.dist.BucketedGradSync); armed per call
         self.grad_sync = None
-        self._warned_autocast = False
 
     # ------------------------------------------------------------------ parameter plumbing
     def _device(self):
@@ -161,11 +174,11 @@ class EncoderRuntime:
             self._wcache_key = key
         return self._wcache
 
-    def _rope_tables(self, max_pos: int, dev):
-        k = (max_pos, str(dev))
+    def _rope_tables(self, max_pos: int, dev, head_dim: int = 64):
+        k = (max_pos, str(dev), head_dim)
         if k not in self._rope:
-            self._rope[k] = (rope_table(max_pos, 64, self.geom.global_rope_theta, dev),
-                             rope_table(max_pos, 64, self.geom.local_rope_theta, dev))
+            self._rope[k] = (rope_table(max_pos, head_dim, self.geom.global_rope_theta, dev),
+                             rope_table(max_pos, head_dim, self.geom.local_rope_theta, dev))
         return self._rope[k]
 
     # ------------------------------------------------------------------ gradients
@@ -219,6 +232,16 @@ class EncoderRuntime:
     def forward_impl(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool, lengths=None):
         return self.forward_many_impl([(input_ids, attention_mask)], save, lengths)
 
+    @staticmethod
+    def precision() -> str:
+        """What the reference computes in: bf16 inside ``torch.autocast("cuda", torch.bfloat16)`` -- its trainer,
+        ref:src/train/cli/train_v33_ddp.py:337 --, fp32 otherwise (bare ``model(...)``, ref:src/model/splade_modern.py:50-88,
+        and the inference encoder, ref:benchmark/encoders.py:309-345).  SNX_PRECISION=bf16|fp32 overrides."""
+        forced = os.environ.get("SNX_PRECISION", "auto")
+        if forced in ("bf16", "fp32"):
+            return forced
+        return "bf16" if (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16) else "fp32"
+
     def forward_many_impl(self, pairs, save: bool, lengths=None):
         """One native forward over several [B_i, S_i] batches laid end to end (sequence groups).
         -> sparse [sum B_i, V], token_weights [sum B_i*S_i] (flat, padded layout), arena, aux.
@@ -226,13 +249,9 @@ class EncoderRuntime:
         -- only the valid tokens are gathered and computed (the kernels take cu_seqlens); the
         lengths come from the host-side collator output, so no device sync is needed."""
         dev = self._device()
-        if not self._warned_autocast and not (torch.is_autocast_enabled("cuda")
-                                              and torch.get_autocast_dtype("cuda") == torch.bfloat16):
-            self._warned_autocast = True
-            logger.warning("SPLADEModernBERT (snx backend) always computes with the bf16 cast points of the reference's "
-                           "training path (autocast(cuda, bf16), ref:train_v33_ddp.py:337); it was called outside bf16 "
-                           "autocast, where the reference would compute in fp32 -- expect |delta| ~1e-2 on sparse weights "
-                           "(see INTEGRATION.md, 'precision outside autocast')")
+        fp32 = self.precision() == "fp32"
+        if not fp32:
+            self.geom.check_supported()
         shapes = []
         for ids, mask in pairs:
             if ids.dim() != 2 or mask.shape != ids.shape:
@@ -297,34 +316,44 @@ class EncoderRuntime:
             cu, pos, groups = lay
             T = T_pad
             smax = max(S for _, S in shapes)
+        hd = self.geom.hidden_size // self.geom.num_attention_heads
         with torch.cuda.device(dev):            # native launches go to THIS device's current stream
-            rg, rl = self._rope_tables(max(smax, 64), dev)
-            wc = self._weights()
-            nbytes = fn("snx_model_workspace_bytes")(C.byref(self._desc), T, nseq, int(save))
-            saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rg, rl = self._rope_tables(max(smax, 64), dev, hd)
             sparse = torch.empty((nseq, self.geom.vocab_size), dtype=torch.float32, device=dev)
             tw = torch.empty((T,), dtype=torch.float32, device=dev)
-            check(fn("snx_model_forward")(C.byref(self._desc), self._param_ptrs(), _p(wc), _p(ids), _p(mask), _p(cu),
-                                          _p(pos), _p(rg), _p(rl), _p(saved), _p(sparse), _p(tw),
-                                          groups if (len(shapes) > 1 or lengths is not None) else None, T, nseq, smax,
-                                          SNX_FWD_SAVE_FOR_BACKWARD if save else 0, _stream()), "snx_model_forward")
+            if fp32:
+                nbytes = fn("snx_model_workspace_bytes_f32")(C.byref(self._desc), T, nseq, int(save))
+                saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                check(fn("snx_model_forward_f32")(C.byref(self._desc), self._param_ptrs(), _p(ids), _p(mask), _p(cu), _p(pos),
+                                                  _p(rg), _p(rl), _p(saved), _p(sparse), _p(tw), T, nseq,
+                                                  SNX_FWD_SAVE_FOR_BACKWARD if save else 0, _stream()), "snx_model_forward_f32")
+            else:
+                wc = self._weights()
+                nbytes = fn("snx_model_workspace_bytes")(C.byref(self._desc), T, nseq, int(save))
+                saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                check(fn("snx_model_forward")(C.byref(self._desc), self._param_ptrs(), _p(wc), _p(ids), _p(mask), _p(cu),
+                                              _p(pos), _p(rg), _p(rl), _p(saved), _p(sparse), _p(tw),
+                                              groups if (len(shapes) > 1 or lengths is not None) else None, T, nseq, smax,
+                                              SNX_FWD_SAVE_FOR_BACKWARD if save else 0, _stream()), "snx_model_forward")
         if scatter is not None:                      # token_weights back to the padded layout (0 at padding)
             tw_full = torch.zeros((T_pad,), dtype=torch.float32, device=dev)
             tw_full[scatter] = tw
             tw = tw_full
-        aux = (ids, mask, cu, pos, rg, rl, T, nseq, smax, groups)
+        aux = (ids, mask, cu, pos, rg, rl, T, nseq, smax, groups, fp32)
         return sparse, tw, saved, aux
 
     def routing_rows(self, saved: torch.Tensor, aux) -> torch.Tensor:
         """Arg-max sequence position per (sequence, vocab) entry chosen by the fused max-pool
         ([B, V] int64; entries whose pooled value is 0 carry no gradient)."""
         T, B = aux[6], aux[7]
+        if aux[10]:
+            raise NotImplementedError("routing_rows: bf16 path only (the fp32 path keeps 64-bit keys)")
         off = fn("snx_model_keys_offset")(C.byref(self._desc), T, B)
         keys = saved[off:off + B * self.geom.vocab_size * 4].view(torch.int32).view(B, -1).to(torch.int64) & 0xFFFFFFFF
         return 0xFFFF - (keys & 0xFFFF)
 
     def backward_impl(self, saved: torch.Tensor, aux, g_sparse: torch.Tensor, sync_token=None):
-        ids, mask, cu, pos, rg, rl, T, B, S, groups = aux  # B = total sequences, S = longest
+        ids, mask, cu, pos, rg, rl, T, B, S, groups, fp32 = aux  # B = total sequences, S = longest
         dev = self._device()
         if g_sparse.shape != (B, self.geom.vocab_size):
             raise ValueError("bad gradient shape")
@@ -342,15 +371,29 @@ class EncoderRuntime:
             ret = grads
         sync = self.grad_sync if (self.direct_grads and self.grad_sync is not None) else None
         with torch.cuda.device(dev):
-            nbytes = fn("snx_model_bwd_workspace_bytes")(C.byref(self._desc), T, B, S)
-            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            args = (C.byref(self._desc), self._param_ptrs(), self._grad_ptrs(grads), _p(self._weights()), _p(ids),
-                    _p(mask), _p(cu), _p(pos), _p(rg), _p(rl), _p(saved), _p(g), _p(scratch), groups, T, B, S)
+            if fp32:
+                nbytes = fn("snx_model_bwd_workspace_bytes_f32")(C.byref(self._desc), T)
+                scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                args32 = (C.byref(self._desc), self._param_ptrs(), self._grad_ptrs(grads), _p(ids), _p(mask), _p(cu), _p(pos),
+                          _p(rg), _p(rl), _p(saved), _p(g), _p(scratch), T, B)
+            else:
+                nbytes = fn("snx_model_bwd_workspace_bytes")(C.byref(self._desc), T, B, S)
+                scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                args = (C.byref(self._desc), self._param_ptrs(), self._grad_ptrs(grads), _p(self._weights()), _p(ids),
+                        _p(mask), _p(cu), _p(pos), _p(rg), _p(rl), _p(saved), _p(g), _p(scratch), groups, T, B, S)
 
             def run_all():
-                check(fn("snx_model_backward")(*args, _stream()), "snx_model_backward")
+                if fp32:
+                    check(fn("snx_model_backward_f32")(*args32, _stream()), "snx_model_backward_f32")
+                else:
+                    check(fn("snx_model_backward")(*args, _stream()), "snx_model_backward")
 
             def run_units(ub, ue):
+                if fp32:                        # one native call; the exchange stream then waits for the launch stream
+                    if ub == 0:
+                        run_all()
+                    sync.stream.wait_stream(torch.cuda.current_stream(dev))
+                    return
                 # the native call makes the exchange stream wait for the launch stream and the weight-gradient stream
                 check(fn("snx_model_backward_units")(*args, ub, ue, C.c_void_p(sync.stream.cuda_stream), _stream()),
                       "snx_model_backward_units")
@@ -361,7 +404,8 @@ class EncoderRuntime:
                 # gradient exchange overlapped with the LAST backward of an armed micro-step (BucketedGradSync): after
                 # each unit range its finished slice of the flat gradient is reduced on the exchange stream while the
                 # next range computes; while it runs the persistent kernels leave CUs to RCCL's channel workgroups
-                reserve = sync.reserved_cus if (sync.armed and sync_token == sync.epoch and sync.outstanding == 1) else 0
+                reserve = sync.reserved_cus if (not fp32 and sync.armed and sync_token == sync.epoch
+                                                and sync.outstanding == 1) else 0
                 if reserve:
                     fn("snx_set_reserved_cus")(reserve)
                 try:

@@ -1,0 +1,189 @@
+"""fp32 execution (csrc/f32_path.hip): the HIP path against the REFERENCE's own fp32 outputs, directly.
+
+The reference computes in bf16 only inside the trainer's autocast block (ref:src/train/cli/train_v33_ddp.py:337); a
+bare ``SPLADEModernBERT.forward`` (ref:src/model/splade_modern.py:50-88) and the inference encoder
+(ref:benchmark/encoders.py:309-345) run fp32.  Outside autocast this repo now runs its fp32 kernels, so the tolerance
+protocol's first leg (<= 1e-5 abs on the tiny configuration, top-k indices exact) and the north
+star's literal "values within 1e-3, top-k bit-exact" can be asserted against the golden vectors captured from the
+reference itself (tools/make_golden.py): g1 = tiny forward / loss / all gradients, g3 / g7 / g8 = the 149 M model.
+Needs a real MI355X: pytest -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+OUT = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _report(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_report.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **obj}) + "\n")
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (130, 70, 50), (777, 192, 64), (4096, 512, 96), (33, 1000, 256)])
+def test_gemm_f32_all_operand_layouts(dev, M, N, K):
+    """One strided kernel serves nn.Linear's forward (NT), dX (NN) and dW (TN, accumulating) in fp32."""
+    import ctypes as C
+    from snx._lib import check, fn
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = torch.randn(N, K, generator=g).to(dev)
+    r = torch.randn(M, N, generator=g).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    # forward + residual: y = r + x w^T
+    y = torch.empty(M, N, device=dev)
+    check(fn("snx_gemm_f32")(P(x), K, 1, P(w), K, 1, P(y), N, P(r), N, M, N, K, 0, st), "gemm fwd")
+    ref = r.double() + x.double() @ w.double().t()
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, K ** 0.5 / 4)
+    # dX = dy w  (dy [M, N], w [N, K])
+    dy = torch.randn(M, N, generator=torch.Generator().manual_seed(5)).to(dev)
+    dx = torch.empty(M, K, device=dev)
+    check(fn("snx_gemm_f32")(P(dy), N, 1, P(w), 1, K, P(dx), K, None, 0, M, K, N, 0, st), "gemm dx")
+    ref = dy.double() @ w.double()
+    assert float((dx.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * max(1.0, N ** 0.5 / 4)
+    # dW += dy^T x
+    dw = torch.ones(N, K, device=dev)
+    check(fn("snx_gemm_f32")(P(dy), 1, N, P(x), 1, K, P(dw), K, None, 0, N, K, M, 1, st), "gemm dw")
+    ref = 1.0 + dy.double().t() @ x.double()
+    assert float((dw.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * max(1.0, M ** 0.5 / 4)
+
+
+def _tiny_model(dev):
+    from oracle import splade_oracle as O
+    from tests.test_gpu_model import _build_model
+    z = np.load(os.path.join(G, "g1_tiny_fwd_bwd.npz"))
+    meta = json.load(open(os.path.join(G, "g1_tiny_fwd_bwd.json")))
+    params = {k[3:]: _t(z[k]) for k in z.files if k.startswith("w::")}
+    batch = {k[4:]: _t(z[k]) for k in z.files if k.startswith("in::")}
+    cfg = O.EncoderConfig.tiny()
+    return z, meta, cfg, params, batch, _build_model(cfg, params, dev)
+
+
+def test_tiny_forward_matches_the_reference_fp32(dev):
+    """|sparse_repr - reference| <= 1e-5 abs, token weights likewise, top-k indices exact wherever the
+    reference's own rank gap exceeds the value error; padded positions are exact zeros (g1 holds the edge rows:
+    a single-token row, all-pad local windows)."""
+    z, meta, cfg, params, b, model = _tiny_model(dev)
+    rep = {}
+    with torch.no_grad():
+        for tag, pre in (("q", "query"), ("p", "positive"), ("n", "negative")):
+            sr, tw = model(b[pre + "_input_ids"].to(dev), b[pre + "_attention_mask"].to(dev))
+            sr, tw = sr.cpu(), tw.cpu()
+            ref, ref_tw = _t(z["out::" + tag]), _t(z["out::" + tag + "t"])
+            rep[tag] = {"sparse_max_abs": float((sr - ref).abs().max()), "tw_max_abs": float((tw - ref_tw).abs().max())}
+            assert rep[tag]["sparse_max_abs"] <= 1e-5 and rep[tag]["tw_max_abs"] <= 1e-5, rep
+            assert (tw[b[pre + "_attention_mask"] == 0] == 0).all()
+            tv, ti = torch.topk(ref, 20, dim=-1)
+            ov, oi = torch.topk(sr, 20, dim=-1)
+            gap = (tv[:, :-1] - tv[:, 1:]) > 2e-5
+            ok = gap[:, 1:] & gap[:, :-1]
+            assert torch.equal(ti[:, 1:-1][ok], oi[:, 1:-1][ok])
+            rep[tag]["topk_checked_frac"] = float(ok.float().mean())
+    _report("f32_tiny_forward_vs_reference_g1", rep)
+
+
+def test_tiny_loss_and_all_gradients_match_the_reference_fp32(dev):
+    """The whole micro-step in fp32 (three forwards, SPLADELossV33 with MarginMSE and k = 2 negatives, backward):
+    loss terms and the gradient of EVERY parameter against the reference's autograd (golden g1)."""
+    from src.model.losses import SPLADELossV33
+    z, meta, cfg, params, b, model = _tiny_model(dev)
+    D = lambda t: t.to(dev)   # noqa: E731
+    q, _ = model(D(b["query_input_ids"]), D(b["query_attention_mask"]))
+    p, _ = model(D(b["positive_input_ids"]), D(b["positive_attention_mask"]))
+    n, _ = model(D(b["negative_input_ids"]), D(b["negative_attention_mask"]))
+    for t_ in (q, p, n):
+        t_.retain_grad()
+    lf = SPLADELossV33(**meta["loss_kwargs"]).to(dev)
+    loss, d = lf(anchor_repr=q, positive_repr=p, negative_repr=n.view(q.shape[0], meta["num_negatives"], -1),
+                 global_step=meta["global_step"], teacher_pos_scores=D(b["teacher_pos_scores"]),
+                 teacher_neg_scores=D(b["teacher_neg_scores"]))
+    assert abs(float(loss) - float(z["out::loss"])) <= 2e-5 * max(1.0, abs(float(z["out::loss"])))
+    for k, v in meta["loss_dict"].items():
+        assert float(d[k]) == pytest.approx(v, rel=5e-5, abs=1e-5), k
+    loss.backward()
+    np.testing.assert_allclose(q.grad.cpu().numpy(), z["out::dq"], atol=2e-6, rtol=2e-4)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), z["out::dp"], atol=2e-6, rtol=2e-4)
+    np.testing.assert_allclose(n.grad.cpu().numpy(), z["out::dn"], atol=2e-6, rtol=2e-4)
+    worst = {}
+    for name, prm in model.named_parameters():
+        ref = z["g::" + name]
+        got = prm.grad.cpu().numpy()
+        worst[name] = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-8))
+        assert worst[name] < 5e-4, (name, worst[name])
+    _report("f32_tiny_grads_vs_reference_g1", {"max_rel_to_tensor_max": max(worst.values()), "worst": max(worst, key=worst.get)})
+
+
+@pytest.mark.parametrize("fixture", ["g3_full_fwd_bwd", "g8_full_unsaturated", "g7_cfg5_d512_k4"])
+def test_full_model_forward_matches_the_reference_fp32(dev, fixture):
+    """149 M model against the reference's fp32 outputs: the north star's literal statement -- sparse-vector values
+    within 1e-3 (measured ~1e-5: summation order only), top-k token indices bit-exact wherever the reference's rank
+    gap exceeds the value error -- for q64 / d256 (g3, g8) and for config 5's 512-token documents (g7)."""
+    from oracle import splade_oracle as O
+    from tests.test_gpu_model import _build_model
+    z = np.load(os.path.join(G, fixture + ".npz"))
+    cfg = O.EncoderConfig()
+    params = O.perturb_params(O.init_params(cfg, seed=42), seed=7, bias_mean=-0.2)
+    model = _build_model(cfg, params, dev)
+    b = {k[4:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("in::")}
+    rep = {}
+    with torch.no_grad():
+        for tag, pre in (("q", "query"), ("p", "positive"), ("n", "negative")):
+            sr, tw = model(b[pre + "_input_ids"], b[pre + "_attention_mask"])
+            sr, tw = sr.cpu(), tw.cpu()
+            # the goldens hold the top-256 (values fp32, indices), fp64 sums over the whole vector, the token weights
+            # (fp32) and the whole vector in fp16 (sanity only: its own rounding is ~1e-3)
+            rv, ri = torch.from_numpy(z[f"out::{tag}_topv"]), torch.from_numpy(z[f"out::{tag}_topi"])
+            gv, gi = torch.topk(sr, 256, dim=-1)
+            err = float((gv - rv).abs().max())
+            gap = (rv[:, :-1] - rv[:, 1:]) > 2 * max(err, 1e-6)          # gap[i]: rank i vs i + 1
+            ok = torch.ones(rv.shape[0], 255, dtype=torch.bool)
+            ok[:, 1:] &= gap[:, :-1]
+            ok &= gap
+            twd = float((tw.reshape(-1) - torch.from_numpy(z[f"out::{tag}_tw"]).reshape(-1)).abs().max())
+            ssum = float(((sr.double().sum(-1) - torch.from_numpy(z[f"out::{tag}_sum"])).abs() / torch.from_numpy(z[f"out::{tag}_sum"]).abs()).max())
+            ssq = float(((sr.double().pow(2).sum(-1) - torch.from_numpy(z[f"out::{tag}_sq"])).abs() / torch.from_numpy(z[f"out::{tag}_sq"]).abs()).max())
+            full16 = float((sr - torch.from_numpy(z[f"out::{tag}_full"].astype(np.float32))).abs().max())
+            rep[tag] = {"top256_val_max_abs": err, "top256_checked_frac": float(ok.float().mean()), "tw_max_abs": twd,
+                        "sum_rel": ssum, "sumsq_rel": ssq, "full_vs_fp16_max_abs": full16}
+            assert err <= 1e-3 and twd <= 1e-3 and full16 <= 3e-3, rep[tag]          # the north star's bound ...
+            assert err <= 2e-5 and ssum <= 1e-6 and ssq <= 1e-6, rep[tag]            # ... and what fp32 actually gives
+            assert torch.equal(ri[:, :255][ok], gi[:, :255][ok]), rep[tag]           # top-k token indices bit-exact
+            assert float(ok.float().mean()) > 0.5, rep[tag]
+    _report("f32_full_forward_vs_reference_" + fixture, rep)
+
+
+def test_inference_encoder_runs_in_fp32_like_the_reference(dev, tmp_path):
+    """NeuralSparseEncoderV33 (ref:benchmark/encoders.py:249-402) calls the model outside autocast: the fp32 kernels run
+    (no bf16 cast points) -- its sparse weights equal the fp32 oracle's to 1e-4 on a small local model."""
+    from oracle import splade_oracle as O
+    from tests.test_gpu_model import _build_model, _small_cfg
+    cfg = _small_cfg()
+    params = O.perturb_params(O.init_params(cfg, seed=3), seed=4, scale=2.0, bias_mean=-0.1)
+    model = _build_model(cfg, params, dev)
+    ids, mask = O.synth_ids(5, 48, cfg, torch.Generator().manual_seed(12), ragged=True)
+    with torch.no_grad():
+        ref, ref_tw = O.splade_forward(params, cfg, ids, mask, "fp32")
+        got, got_tw = model(ids.to(dev), mask.to(dev))
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            got_bf16, _ = model(ids.to(dev), mask.to(dev))
+    assert float((got.cpu() - ref).abs().max()) <= 1e-4 and float((got_tw.cpu() - ref_tw).abs().max()) <= 1e-4
+    # and the two precisions really are two paths: the bf16 kernels differ from fp32 at the 1e-3..1e-2 level
+    assert float((got_bf16.cpu() - ref).abs().max()) > 5e-4

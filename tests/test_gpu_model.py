@@ -318,11 +318,12 @@ def test_inference_matches_training_forward(dev, full_setup):
     cfg, params, model = full_setup
     gen = torch.Generator().manual_seed(9)
     ids, mask = O.synth_ids(3, 64, cfg, gen, ragged=True)
-    with torch.no_grad():
-        a, _ = model(ids.to(dev), mask.to(dev))
-    b, _ = model(ids.to(dev), mask.to(dev))
-    assert torch.equal(a, b.detach())
-    assert torch.equal(model.encode(ids.to(dev), mask.to(dev)).detach(), a)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):      # the bf16 kernels (training precision)
+        with torch.no_grad():
+            a, _ = model(ids.to(dev), mask.to(dev))
+        b, _ = model(ids.to(dev), mask.to(dev))
+        assert torch.equal(a, b.detach())
+        assert torch.equal(model.encode(ids.to(dev), mask.to(dev)).detach(), a)
 
 
 def test_forward_many_equals_separate_passes(dev):
@@ -334,8 +335,9 @@ def test_forward_many_equals_separate_passes(dev):
     b = O.synth_batch(5, 40, 150, cfg, gen, k=2, ragged=True)
     pairs = [(b[t + "_input_ids"].to(dev), b[t + "_attention_mask"].to(dev)) for t in ("query", "positive", "negative")]
     m1, m2 = _build_model(cfg, params, dev), _build_model(cfg, params, dev)
-    sep = [m1(i, m) for i, m in pairs]
-    many = m2.forward_many(pairs)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        sep = [m1(i, m) for i, m in pairs]
+        many = m2.forward_many(pairs)
     w = [torch.randn_like(s[0]) for s in sep]
     sum((s[0] * wi).sum() for s, wi in zip(sep, w)).backward()
     sum((s[0] * wi).sum() for s, wi in zip(many, w)).backward()
@@ -404,8 +406,9 @@ def test_unpadded_execution_equals_padded(dev):
     pairs = [(b[t + "_input_ids"].to(dev), b[t + "_attention_mask"].to(dev)) for t in tags]
     lengths = [b[t + "_attention_mask"].sum(1) for t in tags]
     m1, m2 = _build_model(cfg, params, dev), _build_model(cfg, params, dev)
-    pad = m1.forward_many(pairs)
-    pk = m2.forward_many(pairs, lengths)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        pad = m1.forward_many(pairs)
+        pk = m2.forward_many(pairs, lengths)
     w = [torch.randn_like(s[0]) for s in pad]
     sum((s[0] * wi).sum() for s, wi in zip(pad, w)).backward()
     sum((s[0] * wi).sum() for s, wi in zip(pk, w)).backward()
@@ -414,7 +417,7 @@ def test_unpadded_execution_equals_padded(dev):
     for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         cos, rel = _grad_stats(p2.grad, p1.grad)
         assert cos > 0.99999 and rel < 2e-3, (n1, cos, rel)
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         m2.forward_many(pairs, [lengths[0] * 0, lengths[1], lengths[2]])
 
 

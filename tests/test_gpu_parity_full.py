@@ -209,7 +209,7 @@ def test_topk_indices_exact_on_a_fixture_that_bites(dev, full):
         with torch.no_grad():
             model.model.decoder.bias.copy_(bias.to(dev))
         ids, mask = O.synth_ids(4, 256, cfg, torch.Generator().manual_seed(778), ragged=True)
-        with torch.no_grad():
+        with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
             ref, _ = O.splade_forward(p2, cfg, ids, mask, "bf16")
             got, _ = model(ids.to(dev), mask.to(dev))
     finally:
@@ -228,7 +228,7 @@ def test_full_size_values_ulp_statement(dev, full):
     from oracle import splade_oracle as O
     cfg, params, model = full
     ids, mask = O.synth_ids(2, 256, cfg, torch.Generator().manual_seed(777), ragged=True)
-    with torch.no_grad():
+    with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         ref, ref_tw = O.splade_forward(params, cfg, ids, mask, "bf16")
         got, got_tw = model(ids.to(dev), mask.to(dev))
     st, stw = sparse_ulp_stats(got, ref), sparse_ulp_stats(got_tw, ref_tw)
