@@ -29,6 +29,15 @@ __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }   // v_cvt
 // round-trip through bf16 (the "output of a bf16 op" cast point)
 __device__ __forceinline__ float rbf(float x) { return (float)((bf16_t)x); }
 
+// a * b rounded to fp32 on its own: hipcc contracts `a * b + c` (and __fmul_rn, which is just `*`) into an fma where
+// it sees fit, differently from one kernel to the next; torch's eager q * cos + rotate_half(q) * sin rounds each
+// product (hf:196-219), and two kernels that must agree bit for bit need the same arithmetic.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ uint32_t bf16_bits(float x) {
   bf16_t b = (bf16_t)x;
   return (uint32_t)__builtin_bit_cast(unsigned short, b);

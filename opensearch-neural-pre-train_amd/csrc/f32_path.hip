@@ -270,8 +270,8 @@ __global__ void rope_f32_kernel(float* __restrict__ qkv, const f32x2* __restrict
   const f32x2 cs = tab[(long)pos[t] * half + d];
   const float c = cs[0], s = inverse ? -cs[1] : cs[1];
   const float x1 = base[d], x2 = base[d + half];
-  base[d] = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, s));            // x cos + rotate_half(x) sin, products rounded separately
-  base[d + half] = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, s));
+  base[d] = mul_rn(x1, c) - mul_rn(x2, s);            // x cos + rotate_half(x) sin, products rounded separately
+  base[d + half] = mul_rn(x2, c) + mul_rn(x1, s);
 }
 
 // GeGLU (hf:90-91): u = [a | g] along the last dimension (natural order), y = gelu(a) * g

@@ -184,8 +184,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_kernel(
         for (int r = 0; r < 4; ++r) {
           const float c = pre[i * 2 + j][r >> 1][(r & 1) * 2], sn = pre[i * 2 + j][r >> 1][(r & 1) * 2 + 1];
           const float x1 = rbf(acc[i][j][r]), x2 = rbf(acc[i][j + 2][r]);   // Linear output is bf16
-          lo[r] = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, sn));   // products rounded separately, as torch's
-          hi[r] = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));   // q * cos + rotate_half(q) * sin (hf:196-219)
+          lo[r] = mul_rn(x1, c) - mul_rn(x2, sn);   // products rounded separately, as torch's
+          hi[r] = mul_rn(x2, c) + mul_rn(x1, sn);   // q * cos + rotate_half(q) * sin (hf:196-219)
         }
         stg_put(w, lrow, j * 16 + g4, pack4(lo));
         stg_put(w, lrow, (j + 2) * 16 + g4, pack4(hi));

@@ -416,8 +416,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
           for (int r = 0; r < 4; ++r) {
             const float c = (r < 2 ? q0 : q1)[(r & 1) * 2], sn = (r < 2 ? q0 : q1)[(r & 1) * 2 + 1];
             const float a1 = bf2f(x1[k][r]), a2 = bf2f(x2[k][r]);
-            lo[r] = __fsub_rn(__fmul_rn(a1, c), __fmul_rn(a2, sn));   // products rounded separately, as torch's
-            hi[r] = __fadd_rn(__fmul_rn(a2, c), __fmul_rn(a1, sn));   // q * cos + rotate_half(q) * sin (hf:196-219)
+            lo[r] = mul_rn(a1, c) - mul_rn(a2, sn);   // products rounded separately, as torch's
+            hi[r] = mul_rn(a2, c) + mul_rn(a1, sn);   // q * cos + rotate_half(q) * sin (hf:196-219)
           }
           if (row >= M) continue;
           bf16_t* o = e.C + (long)row * N + col0 + d;

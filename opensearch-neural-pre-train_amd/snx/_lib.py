@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must be imported first: libsnx binds to the HIP runtime torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnx.so")
+# SNX_LIB: another build of the same sources (A/B runs of kernel variants on one box); default = the in-tree library
+LIB_PATH = os.environ.get("SNX_LIB") or os.path.join(_HERE, "libsnx.so")
 
 P = C.c_void_p
 I32 = C.c_int32
