@@ -573,13 +573,15 @@ int snx_launch_nt256(int epi, const void* A, const void* B, int M, int N, int K,
   if (g_nt256_min_m < 0) g_nt256_min_m = getenv("SNX_NT256_MIN_M") ? atoi(getenv("SNX_NT256_MIN_M")) : 8192;
   const int on = g_nt256_on, min_m = g_nt256_min_m;
   // Which shapes come here by default (measured at 36,864 rows against the 128x128 kernel, tools/gpu_nt256.py):
-  // wide outputs (>= 6 column tiles: ~20 units per workgroup, short tiles are a small share) with the plain, RoPE
-  // and GeGLU-forward epilogues.  Three column tiles (N = 768) leave 6.75 units per workgroup, i.e. one whole tile
-  // and one or two short ones that cost most of a whole tile's latency-bound K loop, and the two epilogues that
-  // stream a second operand (residual, GeGLU backward) gain nothing from the exposed write-back.
+  // wide outputs (>= 6 column tiles: ~20 units per workgroup, short tiles are a small share) with the RoPE and
+  // GeGLU-forward epilogues, and the plain store from three column tiles on (N = 768: 6.75 units per workgroup, one
+  // whole tile and one or two short ones that cost most of a whole tile's latency-bound K loop -- level with the
+  // 128x128 kernel in the microbenchmark, 0.5 ms per micro-step faster inside the training step, where operands
+  // come cold).  The two epilogues that stream a second operand (residual, GeGLU backward) gain nothing from the
+  // exposed write-back (bench with SNX_NT256_FORCE=2 / 16: -0.2 / -0.4 ms the wrong way).
   // SNX_NT256_FORCE=<bitmask over EPI>: take every eligible shape of those epilogues (A/B runs).
   static const int force = getenv("SNX_NT256_FORCE") ? atoi(getenv("SNX_NT256_FORCE")) : 0;
-  const bool dflt = (epi == EPI_STORE_BF16 || epi == EPI_ROPE || epi == EPI_GEGLU_FWD) && N >= 6 * BN;
+  const bool dflt = ((epi == EPI_ROPE || epi == EPI_GEGLU_FWD) && N >= 6 * BN) || (epi == EPI_STORE_BF16 && N >= 3 * BN);
   if (on != 2 && !dflt && !((force >> epi) & 1)) return SNX_E_SHAPE;   // on = 2 (snx_nt256_configure): take all
   if (!on || M < min_m || (N % 64) || (K % 64) || K < 64) return SNX_E_SHAPE;
   if ((long)M * K * 2 >= (1L << 32) || (long)N * K * 2 >= (1L << 32)) return SNX_E_SHAPE;
