@@ -76,19 +76,19 @@ def cpu_baseline(seconds_budget: float = 30.0):
     """The oracle (CPU restatement of the reference step, fp32, torch CPU threads = host cores given
     to this process) on a bounded sample: B=4 triplets per micro-step, q64/d256 full length."""
     from oracle import splade_oracle as O
-    # every core this process may run on (the GPU box gives one GPU's job a share of the host); the host's own
-    # logical / physical core counts are recorded beside it
+    # The GPU box gives one GPU's job a 16-core share of the host (more threads than that oversubscribe it: with every
+    # core the scheduler reports, the 30-second sample took minutes); the host's own core counts are recorded beside it.
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, avail)
+    cores = max(1, min(16, avail))
     torch.set_num_threads(cores)
     try:
         import psutil
-        host = {"logical": psutil.cpu_count(logical=True), "physical": psutil.cpu_count(logical=False)}
+        host = {"logical": psutil.cpu_count(logical=True), "physical": psutil.cpu_count(logical=False), "affinity": avail}
     except Exception:
-        host = {"logical": os.cpu_count(), "physical": None}
+        host = {"logical": os.cpu_count(), "physical": None, "affinity": avail}
     cfg = O.EncoderConfig()
     params = O.init_params(cfg, seed=42)
     st = O.TrainState(params)

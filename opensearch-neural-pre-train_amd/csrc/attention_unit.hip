@@ -239,6 +239,17 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_fwd_unit_kernel(const bf1
   }
 }
 
+#ifdef SNX_ATTN_TRACE
+// diagnostics build (-DSNX_ATTN_TRACE, tools/gpu_attn_trace.py): shader-clock stamps of wave 0 of every workgroup of
+// the dQ kernel: entry, images loaded (after the barrier), row groups done, exit -- plus the constant-rate clock
+__device__ unsigned long long* g_attn_trace = nullptr;
+extern "C" int snx_attn_trace_set(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &buf, sizeof(buf)); }
+#define ATRACE(k) if (threadIdx.x == 0 && g_attn_trace) g_attn_trace[8l * blockIdx.x + (k)] = __builtin_amdgcn_s_memtime()
+#define ATRACE_RT(k) if (threadIdx.x == 0 && g_attn_trace) g_attn_trace[8l * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define ATRACE(k)
+#define ATRACE_RT(k)
+#endif
 // --------------------------------------------------------------------------------------- backward dQ
 __global__ __launch_bounds__(NTMAX * 128, 4) void attn_bwd_dq_unit_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_bwd_dq_unit_kernel(
     const int64_t* __restrict__ mask, bf16_t* __restrict__ dqkv, const f32x2* __restrict__ rope_tab,
     const int32_t* __restrict__ pos, int T, int heads, int window, float scale, const UnitSched sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  ATRACE(0); ATRACE_RT(4);
   const Slot t = slot_of_block<2>(sched, cu_seqlens, heads);
   const int ntu = t.ntu;
   char* sK = smem + t.slot * 2 * ntu * TILE_BYTES;
@@ -264,6 +276,7 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_bwd_dq_unit_kernel(
     load_valid(mask, t, sValid, sAll);
   }
   __syncthreads();
+  ATRACE(1);
   if (!t.live) return;
 #pragma unroll 1
   for (int rg = t.lw; rg < ntu * 4; rg += t.wpu) {          // this wave's 16-row groups
@@ -346,7 +359,9 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_bwd_dq_unit_kernel(
     bf16_t* orow = dqkv + (long)(s0 + qpos) * rs + head * 64 + g * 4;
     store_grad_rows(orow, dq, scale, rope_tab, rope_p, g);
   }
+  ATRACE(2 + (rg != t.lw));
   }
+  ATRACE_RT(5);
 }
 
 // ------------------------------------------------------------------------------------ backward dK, dV

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of the attention dQ kernel (diagnostics build: SNX_EXTRA_HIPCC_FLAGS=-DSNX_ATTN_TRACE).
+Per workgroup (wave 0): cycles from entry to images-loaded, to the end of its first and second row group; wall ns."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "opensearch-neural-pre-train_amd"))
+import torch  # noqa: E402
+from snx import ops  # noqa: E402
+from snx._lib import lib  # noqa: E402
+
+dev = torch.device("cuda:0")
+heads = 12
+lens = [256] * 128
+cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
+T = int(cu[-1])
+mask = torch.ones(T, dtype=torch.int64, device=dev)
+qkv = torch.randn(T, 3 * heads * 64, device=dev).to(torch.bfloat16)
+dout = torch.randn(T, heads * 64, device=dev).to(torch.bfloat16)
+L = lib()
+fset = L.snx_attn_trace_set
+fset.restype = C.c_int
+fset.argtypes = [C.c_void_p]
+for w in (-1, 64):
+    out, lse = ops.attn_fwd(qkv, cu, mask, 256, heads, w, validate=False)
+    for _ in range(3):
+        ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False)
+    nb = 128 * heads
+    buf = torch.zeros(nb * 8, dtype=torch.int64, device=dev)
+    fset(buf.data_ptr())
+    ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False)
+    torch.cuda.synchronize()
+    fset(0)
+    b = buf.view(nb, 8).cpu()
+    t0, t1, t2, t3, r0, r1 = (b[:, i].double() for i in (0, 1, 2, 3, 4, 5))
+    live = t2 > 0
+    med = lambda x: float(x[live].median())   # noqa: E731
+    print(f"window={w}: load {med(t1 - t0):.0f} cyc, row group 1 {med(t2 - t1):.0f} cyc, row group 2 {med(t3 - t2):.0f} cyc, "
+          f"workgroup wall {med((r1 - r0) * 10):.0f} ns; kernel span {(float(r1.max() - r0.min()) * 10) / 1e3:.1f} us "
+          f"for {nb} workgroups", flush=True)
