@@ -22,14 +22,15 @@
 // XOR-swizzled with (row & 7) on the DMA source and on the read (conflict-free ds_read_b128), + 4 KiB per wave of
 // private staging for the write-back = 160 KiB.
 //
-// Work split without a tail and without inter-workgroup traffic.  The output is cut into UNITS of 64 rows x 256
-// columns, linearised as (tile position in the XCD-aware column-group order of gemm_core.h) x (4 units per tile);
-// workgroup L of 256 takes units [U L / 256, U (L + 1) / 256).  Cutting that range at tile boundaries gives a few
-// whole 256-row tiles plus at most two SHORT tiles of 64, 128 or 192 rows.  A short tile of 64 u rows keeps the
+// Work split without a tail and without inter-workgroup traffic.  Every XCD owns a contiguous run of the tile
+// sequence (the XCD-aware column-group order of gemm_core.h); its 32 workgroups take the run's tiles interleaved,
+// whole rounds of 32 at a time, and the n mod 32 tiles left over are cut into UNITS of 64 rows x 256 columns dealt
+// contiguously: at most two SHORT tiles of 64, 128 or 192 rows per workgroup.  A short tile of 64 u rows keeps the
 // LDS image and the schedule of a whole one: wave group g's rows [32 u g, 32 u (g + 1)) of the tile land in its
 // usual LDS rows (the DMA source rows are remapped, rows past 32 u re-read a valid row), the MFMAs of row tiles
 // that do not exist are skipped (phases of 16, 8 or 0 MFMAs), the write-back stops after u passes.  36,864 token
-// rows x 2,304 columns: 20.25 units per workgroup -> 21 at most (96 % balance; whole tiles only: 6 rounds for 5.06).
+// rows x 2,304 columns: 162 tiles per XCD = 5 rounds of 32 + 2 tiles = 8 units dealt to 8 workgroups (whole tiles
+// only: 6 rounds for 5.06).
 //
 // Epilogue.  The last barrier of a tile is taken BEFORE the write-back by the leading wave group and AFTER it by the
 // trailing one, so both groups write back in the same slot (exposed once, not twice).  Per pass of 32 rows a wave
@@ -98,19 +99,35 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
   const int wm = wave >> 2, wn = wave & 3;                  // wave group (row half) and column of the 2x4 grid
   const int nk = K / BK;
   const int li = lane & 15, g = lane >> 4;
-  const int L = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous logical id
-  // this workgroup's units
-  long x = wk.units * L / gridDim.x;
-  const long xe = wk.units * (L + 1) / gridDim.x;
+  // This workgroup's tiles.  The tile sequence (gemm_core.h tile_of: XCD super-blocks x column groups x row panels)
+  // is cut into one contiguous run per XCD (blockIdx & 7 labels the workgroups that share an L2).  Inside a run the
+  // 32 workgroups of the XCD take tiles INTERLEAVED -- step k: positions 32 k + 0..31 -- so that at any time they
+  // work on neighbouring tiles: the column tiles of a few row panels, whose A panels and B tiles they share through
+  // the L2 (with one contiguous range per workgroup every workgroup streamed an A panel of its own and re-fetched
+  // it for every column tile: 756 MB of fabric traffic per Wqkv launch for 230 MB of operands and results).  The
+  // n mod 32 tiles left at the end of a run are dealt as 64-row units, contiguously: short tiles.
+  const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const long ntiles = wk.units >> 2;
+  const long P0 = ntiles * xcd / 8, P1 = ntiles * (xcd + 1) / 8;
+  const int nrun = (int)(P1 - P0), nround = nrun / per, nleft = nrun - nround * per;
+  int kround = 0;
+  long x = 4 * (P0 + (long)nround * per) + 4L * nleft * jw / per;            // leftover units of this workgroup
+  const long xe = 4 * (P0 + (long)nround * per) + 4L * nleft * (jw + 1) / per;
 
-  auto next_tile = [&]() __attribute__((always_inline)) {                                  // tile starting at unit x (u = 0: none); advances x
+  auto next_tile = [&]() __attribute__((always_inline)) {                                  // u = 0: none
     Tile t;
     t.m0 = 0; t.n0 = 0; t.u = 0;
+    int pm, pn;
+    if (kround < nround) {
+      tile_of(wk.order, (int)(P0 + (long)kround * per + jw), pm, pn);
+      ++kround;
+      t.m0 = pm * BM; t.n0 = pn * BN; t.u = 4;
+      return t;
+    }
     if (x >= xe) return t;
     const int q0 = (int)(x & 3);
     const long left = xe - x;
     t.u = 4 - q0 < left ? 4 - q0 : (int)left;
-    int pm, pn;
     tile_of(wk.order, (int)(x >> 2), pm, pn);
     t.m0 = pm * BM + q0 * 64;
     t.n0 = pn * BN;
