@@ -401,6 +401,38 @@ def test_gemm_tn_256_form(dev, M):
             assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("reserved", [8, 16, 32, 29])
+def test_gemm_tn_256_with_reserved_cus(dev, reserved):
+    """While a gradient bucket is exchanged the persistent dW kernel leaves CUs to RCCL's channel workgroups
+    (snx_set_reserved_cus: 256 - n workgroups, n rounded up to whole rounds of the 8 XCDs).  Its schedule (one long
+    item per workgroup + stream-K tail) must balance any count: same fp32 reference as test_gemm_tn_256_form at 248 /
+    240 / 224 workgroups, alone and as the layer group of the training step (which no longer fits 248 pieces x tiles
+    exactly)."""
+    from snx._lib import fn
+    ops = _ops()
+    M = 12288
+    g = torch.Generator().manual_seed(reserved)
+    mk = lambda r, c, s=0.1: (torch.randn(r, c, generator=g) * s).to(dev).to(BF16)   # noqa: E731
+    assert fn("snx_set_reserved_cus")(reserved) == 0
+    try:
+        assert fn("snx_get_reserved_cus")() == (reserved + 7) // 8 * 8
+        for shapes in ([(2304, 768), (2304, 768), (768, 1152), (768, 768)], [(768, 384)]):
+            probs, refs = [], []
+            for N, K in shapes:
+                dy, x = mk(M, N), mk(M, K, 1.0)
+                dw = torch.randn(N, K, generator=g).to(dev)
+                refs.append(dw + dy.float().t() @ x.float())
+                probs.append((dy, x, dw, False))
+            ops.gemm_tn_accum_group(probs)
+            for (dy, x, dw, _), ref in zip(probs, refs):
+                err = (dw - ref).abs().max().item()
+                assert err < 2e-3 * max(1.0, ref.abs().max().item()), (reserved, err)
+    finally:
+        fn("snx_set_reserved_cus")(0)
+    assert fn("snx_set_reserved_cus")(-1) != 0 and fn("snx_set_reserved_cus")(129) != 0      # argument check
+    assert fn("snx_get_reserved_cus")() == 0
+
+
 @pytest.mark.parametrize("M", [8192 + 64, 8192 + 37])
 def test_gemm_tn_256_layout(dev, M):
     """Exact check of the 256x256 form: dY = a 0/1 selection pattern, so dW[n, :] = X[row(n), :] bit for bit
