@@ -570,7 +570,11 @@ static int launch(const void* A, const void* B, int M, int N, int K, const EpiAr
     done[devid] = true;
   }
   (void)attr;
-  hipLaunchKernelGGL(kern, dim3(NWG), dim3(512), LDS_TOTAL, st, (const bf16_t*)A, (const bf16_t*)B, M, N, K, wk, e);
+  // CUs left to RCCL while a gradient bucket is exchanged (snx_set_reserved_cus, gemm_tn256.hip): this kernel takes
+  // whole CUs too, and a workgroup that finds none free runs its entire share after another has finished -- twice
+  // the launch.  Tiles are dealt in rounds of gridDim / 8 per XCD: any multiple of 8 workgroups works.
+  const int nwg = NWG - snx_get_reserved_cus();
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), LDS_TOTAL, st, (const bf16_t*)A, (const bf16_t*)B, M, N, K, wk, e);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }

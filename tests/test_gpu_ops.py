@@ -433,6 +433,31 @@ def test_gemm_tn_256_with_reserved_cus(dev, reserved):
     assert fn("snx_get_reserved_cus")() == 0
 
 
+@pytest.mark.parametrize("reserved", [0, 8, 32])
+def test_gemm_nt256_with_reserved_cus(dev, reserved):
+    """The 256x256 persistent NT kernel (gemm_nt256.hip) with 256 / 248 / 224 workgroups: bit-equal to the 128x128
+    kernel (both sum k in the same order) on a shape with short tiles and a ragged last panel, plain and residual."""
+    from snx._lib import fn
+    ops = _ops()
+    M, N, K = 9000 + reserved, 768, 384
+    g = torch.Generator().manual_seed(7 + reserved)
+    x = (torch.randn(M, K, generator=g)).to(dev).to(BF16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(BF16)
+    hin = torch.randn(M, N, generator=g).to(dev)
+    fn("snx_nt256_configure")(0, 0)
+    ref, ref_h = ops.gemm_nt(x, w), ops.gemm_nt_resid(x, w, hin)
+    try:
+        fn("snx_nt256_configure")(2, 1024)
+        assert fn("snx_set_reserved_cus")(reserved) == 0
+        got, got_h = ops.gemm_nt(x, w), ops.gemm_nt_resid(x, w, hin)
+        torch.cuda.synchronize()
+    finally:
+        fn("snx_set_reserved_cus")(0)
+        fn("snx_nt256_configure")(1, 8192)
+    assert torch.equal(ref, got) and torch.equal(ref_h, got_h)
+    assert float((got.float() - x.float() @ w.float().t()).abs().max()) < 0.05
+
+
 @pytest.mark.parametrize("M", [8192 + 64, 8192 + 37])
 def test_gemm_tn_256_layout(dev, M):
     """Exact check of the 256x256 form: dY = a 0/1 selection pattern, so dW[n, :] = X[row(n), :] bit for bit
