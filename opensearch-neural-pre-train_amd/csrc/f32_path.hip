@@ -9,9 +9,11 @@
 //
 // This is the precision path, not the throughput path: one 64x64x16 LDS-tiled GEMM kernel with strided operands
 // serves every Linear (forward NT, dX NN, dW TN) and -- with a fused log1p(relu) + max epilogue -- the tied decoder;
-// attention is one wave per (token, head); the routed SPLADE backward and the attention backward use float atomics.
+// the attention forward is MFMA-tiled (head_dim % 8 == 0; one wave per (token, head) otherwise and in the backward); the
+// routed SPLADE backward and the attention backward use float atomics.
 // Training runs under autocast(bf16) in the reference (ref:src/train/cli/train_v33_ddp.py:337) and on the bf16
 // kernels here; the fp32 backward exists for gradient parity at test sizes.
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -370,6 +372,138 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
   if (lane == 0) lse[(long)head * T + t] = l > 0.f ? m + logf(l) : 0.f;
 }
 
+// Tiled form of the forward for head_dim % 8 == 0 (both shipped geometries: 64 and 16) -- what the inference encoder
+// runs.  One workgroup per (sequence, head, 128-query block), four waves of 32 queries, key tiles of 64 rows of K and V
+// in LDS, both contractions on v_mfma_f32_32x32x2_f32 in TRANSPOSED form so that a lane owns one query:
+//   S^T[key, q] = sum_d K[key, d] Q[q, d]      acc element r of lane (c, h): key 32 b + (r & 3) + 8 (r >> 2) + 4 h, query c
+//   O^T[d, q]   = sum_key V[key, d] P[key, q]  the probabilities are consumed from the registers S^T left them in (the
+//                                              k pair of MFMA step (b, r) is keys {.., .. + 4} of the two wave halves)
+// Running maximum / sum / rescale are per lane (two lane-xor-32 exchanges per tile); the contraction over d pairs
+// dimension 8 m + i with 8 m + 4 + i (float4 operand reads).  The wave-per-(token, head) kernel above took 8.3 ms per
+// layer at 64 x 256 tokens (70 % of the fp32 forward); this one is MFMA-shaped work of 13 GFLOP.
+constexpr int AQ = 128, AKT = 64, APITCH = 68;
+
+__global__ __launch_bounds__(256) void attn_f32_fwd_tiled_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
+                                                                 const int64_t* __restrict__ mask, float* __restrict__ out,
+                                                                 float* __restrict__ lse, int T, int heads, int hd, int window,
+                                                                 float scale) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * AKT * APITCH];   // K tile | V tile; the output block at the end
+  float (*sK)[APITCH] = (float (*)[APITCH])sm;
+  float (*sV)[APITCH] = (float (*)[APITCH])(sm + AKT * APITCH);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 31, h = lane >> 5;
+  const int sq = blockIdx.x, head = blockIdx.y;
+  const int s0 = cu[sq], slen = cu[sq + 1] - s0;
+  const long rs = 3L * heads * hd, H = (long)heads * hd;
+  const int mg = hd >> 3, db_n = hd > 32 ? 2 : 1, q4 = hd >> 2;
+  const float* kbase = qkv + (long)s0 * rs + H + head * hd;
+  const float* vbase = kbase + H;
+  for (int q0 = blockIdx.z * AQ; q0 < slen; q0 += gridDim.z * AQ) {
+    const int qp = q0 + wave * 32 + c;
+    const bool qok = qp < slen;
+    f32x4 qr[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      qr[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (m < mg && qok) qr[m] = *(const f32x4*)(qkv + (long)(s0 + qp) * rs + head * hd + 8 * m + 4 * h);
+    }
+    int klo = 0, khi = slen - 1;
+    if (window >= 0) { klo = max(0, q0 - window); khi = min(slen - 1, q0 + AQ - 1 + window); }
+    const int wq_lo = q0 + wave * 32, wq_hi = wq_lo + 31;          // this wave's queries
+    float mrun = -INFINITY, lrun = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    for (int c0 = klo; c0 <= khi; c0 += AKT) {
+      __syncthreads();                                 // the previous tile has been consumed
+      for (int idx = t; idx < AKT * q4; idx += 256) {
+        const int key = idx / q4, j = idx - key * q4;
+        f32x4 kv = (f32x4){0.f, 0.f, 0.f, 0.f}, vv = kv;
+        if (c0 + key <= khi) {
+          kv = *(const f32x4*)(kbase + (long)(c0 + key) * rs + 4 * j);
+          vv = *(const f32x4*)(vbase + (long)(c0 + key) * rs + 4 * j);
+        }
+        *(f32x4*)&sK[key][4 * j] = kv;
+        *(f32x4*)&sV[key][4 * j] = vv;
+      }
+      __syncthreads();
+      if (window >= 0 && (c0 > wq_hi + window || c0 + AKT - 1 < wq_lo - window)) continue;   // wave-uniform
+      const int kb = c0 + lane;
+      const unsigned long long bits = __ballot(kb <= khi && mask[s0 + kb] != 0);
+      f32x16 sa[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sa[0][i] = 0.f; sa[1][i] = 0.f; }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        if (m < mg) {
+          const f32x4 k0 = *(const f32x4*)&sK[c][8 * m + 4 * h], k1 = *(const f32x4*)&sK[32 + c][8 * m + 4 * h];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            sa[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[i], qr[m][i], sa[0], 0, 0, 0);
+            sa[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[i], qr[m][i], sa[1], 0, 0, 0);
+          }
+        }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int dq = qp - (c0 + key);
+          const bool vis = ((bits >> key) & 1ull) && (window < 0 || (dq <= window && -dq <= window));
+          const float sv = vis ? sa[b][r] * scale : -INFINITY;
+          sa[b][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(mrun, mx);
+      const float alpha = mrun == -INFINITY ? 0.f : expf(mrun - mn);
+      float psum = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = sa[b][r] == -INFINITY ? 0.f : expf(sa[b][r] - mn);
+          sa[b][r] = pv;
+          psum += pv;
+        }
+      psum += __shfl_xor(psum, 32, 64);
+      lrun = lrun * alpha + psum;
+      mrun = mn;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v0 = c < hd ? sV[key][c] : 0.f;
+          o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sa[b][r], o[0], 0, 0, 0);
+          if (db_n > 1) {
+            const float v1 = 32 + c < hd ? sV[key][32 + c] : 0.f;
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sa[b][r], o[1], 0, 0, 0);
+          }
+        }
+    }
+    // o[db][r] = O[dimension 32 db + (r & 3) + 8 (r >> 2) + 4 h][query c] (unnormalised): through LDS for row-major stores
+    __syncthreads();
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = 32 * db + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (db < db_n) sm[(wave * 32 + c) * APITCH + d] = lrun > 0.f ? o[db][r] / lrun : 0.f;
+      }
+    __syncthreads();
+    for (int idx = t; idx < AQ * q4; idx += 256) {
+      const int row = idx / q4, j = idx - row * q4;
+      if (q0 + row < slen)
+        *(f32x4*)(out + (long)(s0 + q0 + row) * H + head * hd + 4 * j) = *(const f32x4*)&sm[row * APITCH + 4 * j];
+    }
+    if (h == 0 && qok) lse[(long)head * T + s0 + qp] = lrun > 0.f ? mrun + logf(lrun) : 0.f;
+  }
+}
+
 // dq (written), dk / dv (float atomics into zero-initialised dqkv): p = exp(s - lse), ds = p (dp - delta) scale
 __global__ __launch_bounds__(256) void attn_f32_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                            const float* __restrict__ dout, const float* __restrict__ lse,
@@ -599,8 +733,14 @@ extern "C" int snx_model_forward_f32(const snx_model_desc* d, const void* const*
     RC(linear_fwd(B(s.x_attn[l]), F(p.wqkv(l)), nullptr, B(s.qkv[l]), T, 3 * H, H, st));
     const long nrope = (long)T * 2 * d->heads * (hd / 2);
     LAUNCH1D(rope_f32_kernel, nrope, B(s.qkv[l]), (const f32x2*)(global ? rope_global : rope_local), pos, nrope, d->heads, hd, 0);
-    hipLaunchKernelGGL(attn_f32_fwd_kernel, dim3(cdiv((long)T * d->heads, 4)), dim3(256), 0, st, B(s.qkv[l]), cu_seqlens, seqid,
-                       mask, B(s.attn[l]), B(s.lse[l]), T, d->heads, hd, global ? -1 : d->window, scale);
+    if (hd % 8 == 0 && !getenv("SNX_F32_ATTN_ROWS")) {
+      const int zq = max(1, min(64, cdiv(cdiv(T, nseq), AQ)));
+      hipLaunchKernelGGL(attn_f32_fwd_tiled_kernel, dim3(nseq, d->heads, zq), dim3(256), 0, st, B(s.qkv[l]), cu_seqlens, mask,
+                         B(s.attn[l]), B(s.lse[l]), T, d->heads, hd, global ? -1 : d->window, scale);
+    } else {
+      hipLaunchKernelGGL(attn_f32_fwd_kernel, dim3(cdiv((long)T * d->heads, 4)), dim3(256), 0, st, B(s.qkv[l]), cu_seqlens,
+                         seqid, mask, B(s.attn[l]), B(s.lse[l]), T, d->heads, hd, global ? -1 : d->window, scale);
+    }
     SNX_CHECK_LAUNCH();
     RC(linear_fwd(B(s.attn[l]), F(p.wo(l)), hbuf(2 * l), hbuf(2 * l + 1), T, H, H, st));
     LAUNCH_ROWS(ln_f32_kernel<0>, T, hbuf(2 * l + 1), nullptr, F(p.mlp_norm(l)), B(s.x_mlp[l]), T, H, d->ln_eps);

@@ -187,3 +187,42 @@ def test_inference_encoder_runs_in_fp32_like_the_reference(dev, tmp_path):
     assert float((got.cpu() - ref).abs().max()) <= 1e-4 and float((got_tw.cpu() - ref_tw).abs().max()) <= 1e-4
     # and the two precisions really are two paths: the bf16 kernels differ from fp32 at the 1e-3..1e-2 level
     assert float((got_bf16.cpu() - ref).abs().max()) > 5e-4
+
+
+@pytest.mark.parametrize("heads,hidden,S", [(4, 64, 300), (2, 128, 300), (2, 128, 70)])
+def test_tiled_fp32_attention_on_ragged_and_holed_masks(dev, heads, hidden, S, monkeypatch):
+    """The MFMA-tiled fp32 attention forward (128-query blocks, 64-key tiles; head_dim 16 and 64) against the oracle's
+    fp32 forward (CPU) and against the wave-per-(token, head) kernel it replaces (SNX_F32_ATTN_ROWS=1), on what the
+    goldens do not hold: sequences longer than one query block, lengths that are no multiple of anything, a mask with
+    holes (any mask is legal: ref:src/model/splade_modern.py:76-86 only multiplies by it), local windows that cross
+    tile borders (window +-8 and +-64)."""
+    from oracle import splade_oracle as O
+    from tests.test_gpu_model import _build_model
+    cfg = O.EncoderConfig(vocab_size=600, hidden_size=hidden, intermediate_size=96, num_hidden_layers=4,
+                          num_attention_heads=heads, local_attention=16 if heads == 4 else 128, pad_token_id=599)
+    params = O.perturb_params(O.init_params(cfg, seed=11), seed=12, scale=2.0, bias_mean=-0.1)
+    g = torch.Generator().manual_seed(S)
+    B = 5
+    ids = torch.randint(5, 590, (B, S), generator=g)
+    mask = torch.ones(B, S, dtype=torch.int64)
+    for b, n in enumerate([S, S - 1, max(3, S // 2 + 3), 1, max(2, S - 129)]):
+        mask[b, n:] = 0
+    mask[0, 5:9] = 0                                    # holes
+    mask[2, 0] = 0
+    ids[mask == 0] = cfg.pad_token_id
+    want, want_tw = O.splade_forward(params, cfg, ids, mask, "fp32")
+    model = _build_model(cfg, params, dev).eval()
+    with torch.no_grad():
+        got, got_tw = model(ids.to(dev), mask.to(dev))
+        monkeypatch.setenv("SNX_F32_ATTN_ROWS", "1")
+        rows, rows_tw = model(ids.to(dev), mask.to(dev))
+    scale = float(want.abs().max())
+    err = float((got.cpu() - want).abs().max())
+    err_rows = float((rows.cpu() - want).abs().max())
+    _report("tiled_fp32_attention", {"heads": heads, "hidden": hidden, "S": S, "max_abs_err_vs_oracle": err,
+                                     "rows_kernel_err": err_rows, "scale": scale})
+    assert scale > 0.1
+    assert err <= 1e-5 * max(1.0, scale)
+    assert float((got_tw.cpu() - want_tw).abs().max()) <= 1e-5 * max(1.0, scale)
+    assert float((got - rows).abs().max()) <= 1e-5 * max(1.0, scale)
+    assert float((got_tw - rows_tw).abs().max()) <= 1e-5 * max(1.0, scale)
