@@ -12,6 +12,8 @@
 //   key = bf16_bits(relu(logit)) << 16 | (0xFFFF - s)
 // (unsigned max = largest value, ties -> smallest s: torch's first-index argmax).  The key is
 // saved per (b, v): the backward pass routes the gradient to exactly that row (row a7 of §8).
+#include <cstdlib>
+
 #include "gemm_core.h"
 #include "snx.h"
 
@@ -525,8 +527,157 @@ __global__ __launch_bounds__(256) void splade_bwd_dh_rows_kernel(const int32_t* 
     *(bf16x4*)(out + (i * 64 + lane) * 4) = (bf16x4){f2bf(acc[i][0]), f2bf(acc[i][1]), f2bf(acc[i][2]), f2bf(acc[i][3])};
 }
 
+// Panel form of the gather above for vocabulary-ordered buckets (the default; SNX_SPLADE_DH_PANELS=0: the kernel above).
+// A wave owns RW = 8 rows (accumulators in registers) and walks the vocabulary in panels -- for panel p: for each of its
+// rows: the row's entries below the panel's end -- inside a persistent launch of 8 waves per CU that takes (sequence,
+// 8-row group) items from a prefix table.  Per row the entries are taken in bucket order, as above: same accumulation
+// order, same dHd bits.  A row's next 64 entries (v, c) stay in two registers per row between panels.
+// Measured at the bench's worst case (192 sequences, every one of the 9.6 M (sequence, vocabulary) entries active,
+// tools/gpu_splade_bwd_ab.py): 1.58 instead of 1.84 ms, 11.0 instead of 13.8 GB fetched (W_E rows are shared through
+// the L2 while the waves of a launch are still inside the same panel; they drift apart like a random walk, and 8-16
+// panels are the optimum).  Holding the waves together with a per-panel progress counter (start panel p when all waves
+// have finished p - 2; bounded spin) cost far more than it saved: 9-45 ms per call at 16-128 panels.
+constexpr int RW = 8, GP = 4, DH_WAVES_PER_CU = 8, DH_WGS = 256 * DH_WAVES_PER_CU / 4;
+
+// items[s] = number of RW-row groups of the sequences before s (one workgroup; nseq + 1 entries + the item counter)
+__global__ __launch_bounds__(256) void splade_dh_items_kernel(const int32_t* __restrict__ cu_seqlens, int32_t* __restrict__ items,
+                                                              int nseq, int max_rows) {
+  __shared__ int part[256];
+  const int t = threadIdx.x;
+  const int per = (nseq + 255) / 256;
+  const int b = min(nseq, t * per), e = min(nseq, b + per);
+  int mine = 0;
+  for (int s = b; s < e; ++s) mine += (min(cu_seqlens[s + 1] - cu_seqlens[s], max_rows) + RW - 1) / RW;
+  part[t] = mine;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    items[nseq] = run;
+    items[nseq + 1] = 0;                              // the gather's item counter
+  }
+  __syncthreads();
+  int k = part[t];
+  for (int s = b; s < e; ++s) {
+    items[s] = k;
+    k += (min(cu_seqlens[s + 1] - cu_seqlens[s], max_rows) + RW - 1) / RW;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void splade_bwd_dh_panels_kernel(const int32_t* __restrict__ list_v,
+                                                                   const float* __restrict__ list_c,
+                                                                   const int32_t* __restrict__ row_off,
+                                                                   const int32_t* __restrict__ items,
+                                                                   const bf16_t* __restrict__ W,
+                                                                   const int32_t* __restrict__ cu_seqlens,
+                                                                   bf16_t* __restrict__ dHd, int V, int H, int max_rows,
+                                                                   int nseq, int npanel, int* __restrict__ counter) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nitems = items[nseq];
+  const int pw = (V + npanel - 1) / npanel;
+  // persistent: every wave of the launch is resident from the start.  Items are handed out by a counter, first come
+  // first served: rows of short sequences own more entries each (V / length on average at random init), and a fixed
+  // assignment (wave, wave + all, ...) left the waves with the heavy items a round behind
+#pragma unroll 1
+  while (true) {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(counter, 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= nitems) break;
+    int lo = 0, hi = nseq - 1;                        // the sequence of this item: last s with items[s] <= item
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items[mid] <= item) lo = mid;
+      else hi = mid - 1;
+    }
+    const int seq = lo;
+    const int row0 = (item - items[seq]) * RW;
+    const int s0 = cu_seqlens[seq], slen = cu_seqlens[seq + 1] - s0;
+    const int32_t* ro = row_off + (long)seq * (max_rows + 1);
+    const int32_t* lv = list_v + (long)seq * V;
+    const float* lc = list_c + (long)seq * V;
+    f32x4 acc[RW][NV];
+    int cur[RW], end[RW], cbase[RW];                  // wave-uniform: next entry, end of the bucket, first entry of the chunk
+    int cv[RW];                                       // chunk registers: entry cbase + lane
+    float cc[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int row = row0 + j;
+      const bool live = row < slen && row < max_rows;
+      cur[j] = live ? ro[row] : 0;
+      end[j] = live ? ro[row + 1] : 0;
+      cbase[j] = cur[j];
+      const int e = cbase[j] + lane;
+      cv[j] = e < end[j] ? lv[e] : 0x7FFFFFFF;
+      cc[j] = e < end[j] ? lc[e] : 0.f;
+    }
+#pragma unroll 1
+    for (int p = 0; p < npanel; ++p) {
+      const int vb = p + 1 == npanel ? 0x7FFFFFFF : (p + 1) * pw;
+#pragma unroll
+      for (int j = 0; j < RW; ++j) {
+        while (cur[j] < end[j]) {                     // wave-uniform
+          const int first = cur[j] - cbase[j];
+          const int n = __popcll(__ballot(lane >= first && cv[j] < vb));   // sorted: a run starting at `first`
+          for (int u0 = 0; u0 < n; u0 += GP) {
+            float cb[GP];
+            bf16x4 wv[GP][NV];
+#pragma unroll
+            for (int u = 0; u < GP; ++u) {
+              cb[u] = 0.f;
+#pragma unroll
+              for (int i = 0; i < NV; ++i) wv[u][i] = (bf16x4){0, 0, 0, 0};
+              if (u0 + u < n) {                       // wave-uniform
+                const int src = first + u0 + u;
+                cb[u] = __shfl(cc[j], src, 64);
+                const bf16_t* wrow = W + (long)__shfl(cv[j], src, 64) * H;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) wv[u][i] = *(const bf16x4*)(wrow + (i * 64 + lane) * 4);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < GP; ++u)
+#pragma unroll
+              for (int i = 0; i < NV; ++i) {
+                acc[j][i][0] += cb[u] * bf2f(wv[u][i][0]);
+                acc[j][i][1] += cb[u] * bf2f(wv[u][i][1]);
+                acc[j][i][2] += cb[u] * bf2f(wv[u][i][2]);
+                acc[j][i][3] += cb[u] * bf2f(wv[u][i][3]);
+              }
+          }
+          cur[j] += n;
+          if (first + n < 64) break;                  // the chunk's next entry belongs to a later panel (or the bucket ended)
+          cbase[j] = cur[j];                          // chunk used up: the next 64 entries
+          const int e = cbase[j] + lane;
+          cv[j] = e < end[j] ? lv[e] : 0x7FFFFFFF;
+          cc[j] = e < end[j] ? lc[e] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+      const int row = row0 + j;
+      if (row < slen) {
+        bf16_t* out = dHd + (long)(s0 + row) * H;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          *(bf16x4*)(out + (i * 64 + lane) * 4) =
+              (bf16x4){f2bf(acc[j][i][0]), f2bf(acc[j][i][1]), f2bf(acc[j][i][2]), f2bf(acc[j][i][3])};
+      }
+    }
+  }
+}
+
 extern "C" size_t snx_splade_bwd_scratch_bytes(int32_t nseq, int32_t max_seqlen, int32_t V) {
-  return (size_t)nseq * V * 8 + (size_t)nseq * (max_seqlen + 1) * 4 + 256;
+  return (size_t)nseq * V * 8 + (size_t)nseq * (max_seqlen + 1) * 4 + 256 + ((size_t)nseq + 2) * 4 + 256;
 }
 
 extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* Hd, const void* W,
@@ -562,6 +713,26 @@ extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* 
                        row_off, V, max_seqlen);
   }
   SNX_CHECK_LAUNCH();
+  const char* penv = getenv("SNX_SPLADE_DH_PANELS");   // number of vocabulary panels; 0: the wave-per-row gather (A/B, tests)
+  const int panels = penv ? atoi(penv) : 16;
+  if (det && panels > 0) {
+    int32_t* items = (int32_t*)(sc + (((size_t)nseq * V * 8 + (size_t)nseq * (max_seqlen + 1) * 4 + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(splade_dh_items_kernel, dim3(1), dim3(256), 0, st, cu_seqlens, items, nseq, max_seqlen);
+    SNX_CHECK_LAUNCH();
+    const dim3 pgrid(DH_WGS);
+#define SNX_DH_PANELS(NVV)                                                                                                  \
+  hipLaunchKernelGGL(splade_bwd_dh_panels_kernel<NVV>, pgrid, dim3(256), 0, st, list_v, list_c, row_off, items, (const bf16_t*)W, \
+                     cu_seqlens, (bf16_t*)dHd, V, H, max_seqlen, nseq, panels, items + nseq + 1)
+    switch (H / 256) {
+      case 1: SNX_DH_PANELS(1); break;
+      case 2: SNX_DH_PANELS(2); break;
+      case 3: SNX_DH_PANELS(3); break;
+      default: SNX_DH_PANELS(4); break;
+    }
+#undef SNX_DH_PANELS
+    SNX_CHECK_LAUNCH();
+    return SNX_OK;
+  }
   const dim3 grid(cdiv(max_seqlen, 4), nseq);
   switch (H / 256) {
     case 1: hipLaunchKernelGGL(splade_bwd_dh_rows_kernel<1>, grid, dim3(256), 0, st, list_v, list_c, row_off, (const bf16_t*)W, cu_seqlens, (bf16_t*)dHd, V, H, max_seqlen); break;

@@ -529,7 +529,7 @@ def test_attention_bwd(dev, S, window):
 # tables no longer fit and the bucket pass falls back to first-come slots; (2, 512, 50000, 768): config-5 documents
 @pytest.mark.parametrize("B,S,V,H", [(3, 64, 1000, 256), (4, 256, 3000, 768), (2, 200, 640, 256), (2, 1024, 700, 256),
                                      (1, 1100, 512, 256), (2, 512, 50000, 768)])
-def test_splade_bwd(dev, B, S, V, H):
+def test_splade_bwd(dev, B, S, V, H, monkeypatch):
     ops = _ops()
     from snx._lib import fn, check
     from snx.ops import _p, _stream
@@ -551,6 +551,15 @@ def test_splade_bwd(dev, B, S, V, H):
     scratch = torch.empty(fn("snx_splade_bwd_scratch_bytes")(B, S, V), dtype=torch.uint8, device=dev)
     check(fn("snx_splade_bwd")(_p(gs.to(dev)), _p(keys), _p(hdd), _p(Wd), _p(cud), _p(dHd), _p(gE), _p(gb),
                                _p(scratch), T, B, S, V, H, _stream()), "snx_splade_bwd")
+    # the dHd gather has two forms (one wave per row / eight rows per wave walking the vocabulary in panels, the default
+    # for vocabulary-ordered buckets): same accumulation order per row, so the same bits
+    dHd_rows = torch.full((T, H), float("nan"), dtype=BF16, device=dev)
+    monkeypatch.setenv("SNX_SPLADE_DH_PANELS", "0")
+    gE2, gb2 = gE0.clone(), gb0.clone()
+    check(fn("snx_splade_bwd")(_p(gs.to(dev)), _p(keys), _p(hdd), _p(Wd), _p(cud), _p(dHd_rows), _p(gE2), _p(gb2),
+                               _p(scratch), T, B, S, V, H, _stream()), "snx_splade_bwd")
+    monkeypatch.delenv("SNX_SPLADE_DH_PANELS")
+    assert torch.equal(dHd.view(torch.int16), dHd_rows.view(torch.int16))
     # dense reference through autograd on the bf16 logits
     hl = hdd.float().requires_grad_(True)
     Wl = Wd.float().requires_grad_(True)
