@@ -42,6 +42,13 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def rccl() -> bool:
+    """True when the default group is RCCL (backend string "nccl").  Device tensors under any other backend (gloo:
+    `tests/test_gpu_dist.py` runs two ranks on ONE GPU that way, which RCCL refuses) are exchanged through host
+    copies made on the exchange stream -- same ordering, no device collectives."""
+    return dist.get_backend() == "nccl"
+
+
 def allreduce_flat_grads(flat: torch.Tensor, bucket_mb: int = 0) -> None:
     """Average `flat` across ranks in place.  On GPU the collective(s) run on a dedicated stream
     ordered after the gradient producers; the compute stream waits on them before the optimizer.
@@ -56,7 +63,11 @@ def allreduce_flat_grads(flat: torch.Tensor, bucket_mb: int = 0) -> None:
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            if bucket_mb and bucket_mb > 0:
+            if not rccl():
+                host = flat.cpu()                        # stream-ordered copy: waits for the producers `side` waits for
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                flat.copy_(host.div_(w))
+            elif bucket_mb and bucket_mb > 0:
                 step = bucket_mb * 1024 * 1024 // 4
                 for o in range(0, flat.numel(), step):
                     dist.all_reduce(flat[o:o + step], op=dist.ReduceOp.AVG)
@@ -168,6 +179,11 @@ class BucketedGradSync:
     def _reduce(self, t: torch.Tensor) -> None:
         """Average the 1-D fp32 slice `t` over ranks in place (current stream / program order)."""
         w = world()
+        if t.is_cuda and not rccl():                     # host-staged (see rccl())
+            host = t.cpu()
+            self._reduce(host)
+            t.copy_(host)
+            return
         gpu = t.is_cuda
         if self.mode == "rs_ag" and t.numel() >= w:
             chunk = t.numel() // w
@@ -238,22 +254,28 @@ class _AllGatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: torch.Tensor):
         w = world()
+        ctx.rows = x.shape[0]
+        if x.is_cuda and not rccl():                     # host-staged (see rccl())
+            host = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype)
+            dist.all_gather_into_tensor(host, x.contiguous().cpu())
+            return host.to(x.device)
         out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x.contiguous())
-        ctx.rows = x.shape[0]
         return out
 
     @staticmethod
     def backward(ctx, g: torch.Tensor):
         w = world()
         g = g.contiguous()
-        if g.is_cuda:
+        if g.is_cuda and rccl():
             out = torch.empty((ctx.rows,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
             dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
             return out
+        dev = g.device
+        g = g.cpu() if g.is_cuda else g
         dist.all_reduce(g, op=dist.ReduceOp.SUM)          # gloo has no reduce_scatter
         r = rank()
-        return g[r * ctx.rows:(r + 1) * ctx.rows].clone()
+        return g[r * ctx.rows:(r + 1) * ctx.rows].clone().to(dev)
 
 
 def all_gather_with_grad(x: torch.Tensor) -> torch.Tensor:

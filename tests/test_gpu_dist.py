@@ -220,3 +220,45 @@ def test_cli_trains_end_to_end_under_torchrun(dev, tmp_path, extra):
     assert ck == ["config.json", "model.pt", "training_state.pt"]
     sd = torch.load(out / "final_model" / "model.pt", map_location="cpu", weights_only=True)
     assert "model.decoder.weight" in sd and all(torch.isfinite(v).all() for v in sd.values())
+
+
+def test_two_ranks_share_one_gpu(dev, tmp_path):
+    """World size 2 on the GPU path.  Two processes, both on cuda:0, gloo group (RCCL refuses two ranks on one device;
+    snx.dist then moves the buckets through host copies made on the exchange stream): rank 1 starts from other
+    weights (rank-0 broadcast), the ranks see different batches, and after the first accumulation window every
+    gradient must be the mean of the two ranks' local gradients (computed without any exchange) and bit-equal on
+    both ranks; after two optimizer steps the parameters must be bit-equal on both ranks.  Fused pass and the
+    reference's three-forward pattern, all_reduce and reduce-scatter + all-gather forms, cross-GPU negatives once.
+    See tests/two_rank_gpu_worker.py."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "opensearch-neural-pre-train_amd")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, pkg, os.environ.get("PYTHONPATH", "")]),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("SNX_DIST_FORCE", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.two_rank_gpu_worker", str(r), str(port), str(tmp_path)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=root)
+             for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=420))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, (r, so[-1500:], se[-3000:])
+    reps = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    assert all(len(rep["cases"]) == 4 for rep in reps)
+    out = os.path.join(root, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.jsonl"), "a") as f:
+        f.write(json.dumps({"test": "two_ranks_share_one_gpu", "rank0": reps[0]["cases"]}) + "\n")

@@ -1,0 +1,117 @@
+"""Worker of tests/test_gpu_dist.py::test_two_ranks_share_one_gpu: one of TWO data-parallel ranks that run the native
+training path (HIP kernels, flat gradient, bucketed exchange overlapped with the backward, fused clip + AdamW) on the
+SAME MI355X.  RCCL refuses two ranks on one device, so the process group is gloo and snx.dist moves the buckets through
+host copies made on the exchange stream (snx.dist.rccl): what is exercised is everything around the collective -- the
+rank-0 broadcast, which backward exchanges, the stream ordering between the producers of a bucket and its exchange, the
+wait before the optimizer -- with world size 2 and different data per rank.
+
+usage: python -m tests.two_rank_gpu_worker RANK PORT OUTDIR"""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+
+def main(rank: int, port: int, outdir: str) -> None:
+    from oracle import splade_oracle as O
+    from src.model.losses import SPLADELossV33
+    from src.train.config.v33 import V33Config
+    from src.train.core import ddp_trainer as T
+    from tests.test_gpu_model import _build_model, _small_cfg
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+    cfg = _small_cfg()
+    params = O.perturb_params(O.init_params(cfg, seed=3), seed=4, scale=2.0, bias_mean=-0.1)
+    mine = {k: (v if rank == 0 else v * 1.01 + 0.001) for k, v in params.items()}     # rank 1 starts elsewhere
+    gen = torch.Generator().manual_seed(500 + rank)                                     # different data per rank
+    batches = [O.synth_batch(4, 24, 70, cfg, gen, k=1, ragged=True) for _ in range(4)]
+    conf = V33Config()
+    conf.training.gradient_accumulation_steps = 2
+    conf.training.learning_rate = 1e-3
+    report = {"rank": rank, "cases": []}
+
+    def mean_over_ranks(t: torch.Tensor) -> torch.Tensor:
+        c = t.detach().float().cpu().clone()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        return c / 2
+
+    def same_on_both_ranks(t: torch.Tensor) -> bool:
+        c = t.detach().float().cpu().contiguous()
+        both = [torch.empty_like(c), torch.empty_like(c)]
+        dist.all_gather(both, c)
+        return torch.equal(both[0], both[1])
+
+    for fused, mode, xneg in ((True, "allreduce", False), (False, "allreduce", False), (True, "rs_ag", False),
+                              (False, "rs_ag", True)):
+        os.environ["SNX_FUSED_PASSES"] = "1" if fused else "0"
+        os.environ["SNX_GRAD_EXCHANGE"] = mode
+        # local gradients of the first window, no exchange: an unwrapped model (autograd .grad) on rank 0's weights
+        plain = _build_model(cfg, params, dev)
+        loss_fn = SPLADELossV33(temperature=20.0, flops_warmup_steps=4).to(dev)
+        local = None
+        if not xneg:
+            for b in batches[:2]:
+                T.micro_step(plain, loss_fn, b, 0, dev, 2)
+            local = {n: p.grad.detach().clone() for n, p in plain.named_parameters()}
+        del plain
+        # the data-parallel run
+        model = T.NativeDataParallel(_build_model(cfg, mine, dev), n_buckets=3)
+        for n, p in model.module.named_parameters():
+            assert torch.equal(p.detach().cpu(), params[n].to(p.dtype)), f"broadcast: {n} differs from rank 0's"
+        gsync = model.module.runtime.grad_sync
+        assert gsync.mode == mode
+        gsync.keep_log = True
+        loss_fn = SPLADELossV33(temperature=20.0, flops_warmup_steps=4).to(dev)
+        opt = T.build_optimizer(model, conf)
+        sch = T.build_scheduler(opt, 0, 4)
+        step, worst = 0, 0.0
+        for i, b in enumerate(batches):
+            last = (i + 1) % 2 == 0
+            loss, _ = T.micro_step(model, loss_fn, b, step, dev, 2, cross_gpu_negatives=xneg, last_of_window=last)
+            assert torch.isfinite(loss)
+            if last:
+                if step == 0 and local is not None:
+                    model.sync_gradients()                  # wait for the overlapped exchange
+                    torch.cuda.synchronize()
+                    for n, p in model.module.named_parameters():
+                        want = mean_over_ranks(local[n])
+                        got = p.grad.detach().float().cpu()
+                        err = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-12)
+                        worst = max(worst, err)
+                        assert err <= 2e-4, f"{n}: averaged gradient off by {err:.3g} of its maximum"
+                        assert same_on_both_ranks(p.grad), f"{n}: gradient differs between the ranks"
+                T.optimizer_step(model, opt, sch, conf)
+                step += 1
+        torch.cuda.synchronize()
+        for n, p in model.module.named_parameters():
+            assert same_on_both_ranks(p), f"{n}: parameters differ between the ranks after {step} optimizer steps"
+            assert torch.isfinite(p).all()
+        nfwd = 1 if fused else 3
+        epochs = sorted({e[1] for e in gsync.log if e[0] == "fwd"})
+        assert len(epochs) == 2, gsync.log
+        total = model.module.runtime.flat_grad.numel()
+        for ep in epochs:
+            i_ex = next(i for i, e in enumerate(gsync.log) if e[0] == "exchange" and e[1] == ep)
+            before = [e for e in gsync.log[:i_ex] if e[0] in ("fwd", "bwd") and e[1] == ep]
+            assert [e[0] for e in before] == ["fwd"] * nfwd + ["bwd"] * nfwd, before
+            reds = []
+            for e in gsync.log[i_ex + 1:]:
+                if e[0] != "reduce":
+                    break
+                reds.append((e[1], e[2]))
+            cov = sorted(reds)
+            assert cov[0][0] == 0 and cov[-1][1] == total and all(a[1] == b[0] for a, b in zip(cov, cov[1:])), cov
+        report["cases"].append({"fused": fused, "mode": mode, "cross_gpu_negatives": xneg,
+                                "worst_avg_grad_err_rel_max": worst})
+        del model, opt, sch
+    dist.barrier()
+    with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
+        json.dump(report, f)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3])
