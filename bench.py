@@ -187,15 +187,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    # SNX_BENCH_BACKEND=gloo: REHEARSAL of the N > 1 launch line on fewer GPUs than ranks (ranks share devices, the
+    # gradient buckets move through host copies: snx.dist.rccl()) -- exercises this file's multi-rank control flow, its
+    # numbers mean nothing.  The measured configuration is one rank per GPU over RCCL.
+    backend = os.environ.get("SNX_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({ndev} visible); one process per GPU")
+    local_dev = local_rank % max(ndev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device(f"cuda:{local_dev}")
     # one process per GPU over RCCL; a 1-rank launch under torchrun with SNX_DIST_FORCE=1 also builds the group, so
     # that the collectives of the data-parallel path can be rehearsed on a single GPU
     use_pg = world > 1 or ("RANK" in os.environ and os.environ.get("SNX_DIST_FORCE", "0") == "1")
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -250,7 +261,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_pg:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     final_loss = float(loss)

@@ -53,3 +53,27 @@ def test_bench_under_torchrun_one_rank_over_rccl():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and math.isfinite(d["config"]["final_loss"]) and 100.0 < d["value"] < 1e5
+
+
+@pytest.mark.gpu
+def test_bench_launch_line_with_two_ranks_rehearsed_on_one_gpu():
+    """The driver's N > 1 command (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) with N = 2
+    on the one GPU a test box has: SNX_BENCH_BACKEND=gloo lets the two ranks share the device (RCCL refuses that) and
+    moves the gradient buckets through host copies, so the multi-rank control flow of bench.py itself runs -- per-rank
+    seeds, rank-0 broadcast at wrap, barriers around the timed region, MAX over ranks, the extra profiled steps that
+    keep the collectives of rank > 0 matched with rank 0's, exactly one JSON line from rank 0.  The value it prints is
+    a rehearsal number (two ranks on one device), only its shape is checked."""
+    env = dict(os.environ, SNX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("SNX_DIST_FORCE",):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "4", "--warmup", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert math.isfinite(d["config"]["final_loss"]) and d["value"] > 0
+    assert "cpu_baseline" not in d                       # rank 0 at N = 1 only
