@@ -22,8 +22,12 @@
 // Sequences meet in the key array through atomicMax (a sequence may span several tiles and both wave rows).
 //
 // Tiles are dealt in blocks of 4 (rows) x 8 (vocab) to the 32 workgroups of an XCD (blockIdx & 7), which walk K
-// in step: the 12 operand panels of a block are shared through that XCD's L2 (5.2 GB of fabric reads per launch of
-// the bench's 192 sequences against 25 GB of LDS-DMA traffic; the 128x128 kernel: 5.7 GB).
+// in step: the 12 operand panels of a block are shared through that XCD's L2.  Round 3: every XCD owns a contiguous
+// run of the blocks in COLUMN-major order, so that its consecutive steps keep the same 8 vocabulary tiles (2.4 MB of
+// W_E, resident in its 4 MiB L2) and only stream new rows of Hd: 2.27 GB of fabric reads per launch of the bench's 192
+// sequences instead of 4.85 (blocks dealt round-robin in row-major order, -DSNX_DEC256_ROUND_ROBIN; the 128x128
+// kernel: 5.7 GB) against 25 GB of LDS-DMA traffic; the time is the same (3.39 ms: the L2 -> LDS path never was the
+// bound).
 //
 // Measured (64 x 64 + 128 x 256 tokens, V = 50,000, in-kernel stamps of a -DSNX_GEMM_TRACE build, tools/gpu_decbench.py):
 // 3.45 ms = 822 TFLOP/s (128x128 kernel: 4.16 ms); per tile 46.9k cycles = 24 half-steps of 1,514 (768 of them MFMA; 1,042
@@ -175,11 +179,22 @@ struct TilePos { int mt, nt; };
 // not exist (the workgroup sits that step out)
 __device__ __forceinline__ TilePos tile_at(int k, int xcd, int j, int mtiles, int ntn) {
   const int nbn = (ntn + 7) >> 3, nbm = (mtiles + 3) >> 2;
-  const int b = xcd + 8 * k;
+  const int nb = nbm * nbn;
   TilePos t;
   t.mt = -1; t.nt = 0;
-  if (b >= nbm * nbn) return t;
+#ifdef SNX_DEC256_ROUND_ROBIN                         // the earlier deal: block xcd + 8 k, row-major
+  const int b = xcd + 8 * k;
+  if (b >= nb) return t;
   const int bm = b / nbn, bn = b - bm * nbn;
+#else
+  // W_E-stationary walk: every XCD owns a contiguous run of the blocks in COLUMN-major order (row blocks fastest), so
+  // that its consecutive steps keep the same 8 vocabulary tiles (2.4 MB of W_E, resident in its L2) and only stream
+  // new rows of Hd
+  const int lo = (int)((long)nb * xcd / 8), hi = (int)((long)nb * (xcd + 1) / 8);
+  const int b = lo + k;
+  if (b >= hi) return t;
+  const int bn = b / nbm, bm = b - bn * nbm;
+#endif
   const int mt = bm * 4 + (j >> 3), nt = bn * 8 + (j & 7);
   if (mt < mtiles && nt < ntn) { t.mt = mt; t.nt = nt; }
   return t;
@@ -207,7 +222,12 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
   const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
   const int nsub = g.hdr[0];
   const int mtiles = (nsub + 7) >> 3;
+#ifdef SNX_DEC256_ROUND_ROBIN
   const int nsteps = (((mtiles + 3) >> 2) * ((g.ntn + 7) >> 3) + 7 - xcd) / 8;   // blocks xcd, xcd + 8, ...
+#else
+  const int nblk = ((mtiles + 3) >> 2) * ((g.ntn + 7) >> 3);
+  const int nsteps = (int)((long)nblk * (xcd + 1) / 8) - (int)((long)nblk * xcd / 8);   // this XCD's run of blocks
+#endif
   const int nh = g.K / HS;                            // half-steps per tile
 
   auto next_tile = [&](int from, TilePos& t) {        // first existing tile with step index >= from, or -1
