@@ -149,6 +149,180 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, TailArgs ta) 
   }
 }
 
+// The same contraction on 128x128x16 tiles for the large problems (the 149 M model's Linears and its decoder at
+// inference): four waves of 64x64 (2 x 2 accumulators of 32x32), operands prefetched into registers one K-tile ahead
+// and stored into the other half of a double-buffered LDS image, one barrier per K-tile.  Every output element is
+// still the k-ascending chain of the 64x64 kernel above: identical bits.
+constexpr int TP2 = 132;             // LDS row pitch of the 128-wide tiles (floats)
+
+// this thread's share of a 128 x 16 operand tile, from global memory into 8 registers ...
+__device__ __forceinline__ void fetch_tile128(const float* __restrict__ P, long s_row, long s_k, int vec, int row0, int nrows,
+                                              int k0, int K, int t, float (&v)[8]) {
+  if (vec && s_k == 1) {                                        // k contiguous: rows r, r + 64; 4 k each
+    const int kk = (t & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (t >> 2) + 64 * i;
+      if (row0 + r < nrows && k0 + kk + 3 < K) {
+        const f32x4 x = *(const f32x4*)(P + (long)(row0 + r) * s_row + k0 + kk);
+        v[4 * i] = x[0]; v[4 * i + 1] = x[1]; v[4 * i + 2] = x[2]; v[4 * i + 3] = x[3];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[4 * i + u] = (row0 + r < nrows && k0 + kk + u < K) ? P[(long)(row0 + r) * s_row + k0 + kk + u] : 0.f;
+      }
+    }
+  } else if (vec && s_row == 1) {                               // rows contiguous: k rows kk, kk + 8; 4 rows each
+    const int r = (t & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kk = (t >> 5) + 8 * i;
+      if (k0 + kk < K && row0 + r + 3 < nrows) {
+        const f32x4 x = *(const f32x4*)(P + (long)(k0 + kk) * s_k + row0 + r);
+        v[4 * i] = x[0]; v[4 * i + 1] = x[1]; v[4 * i + 2] = x[2]; v[4 * i + 3] = x[3];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[4 * i + u] = (k0 + kk < K && row0 + r + u < nrows) ? P[(long)(k0 + kk) * s_k + row0 + r + u] : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = t + i * 256, r = idx & 127, kk = idx >> 7;
+      v[i] = (row0 + r < nrows && k0 + kk < K) ? P[(long)(row0 + r) * s_row + (long)(k0 + kk) * s_k] : 0.f;
+    }
+  }
+}
+// ... and from the registers into the [k][row] image
+__device__ __forceinline__ void put_tile128(long s_row, long s_k, int vec, int t, const float (&v)[8], float (*S)[TP2]) {
+  if (vec && s_k == 1) {
+    const int kk = (t & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (t >> 2) + 64 * i;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) S[kk + u][r] = v[4 * i + u];
+    }
+  } else if (vec && s_row == 1) {
+    const int r = (t & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kk = (t >> 5) + 8 * i;
+      *(f32x4*)&S[kk][r] = (f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = t + i * 256;
+      S[idx >> 7][idx & 127] = v[i];
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g, TailArgs ta) {
+  __shared__ __attribute__((aligned(16))) float As[2][16][TP2];
+  __shared__ __attribute__((aligned(16))) float Bs[2][16][TP2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1, c = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float va[8], vb[8];
+  fetch_tile128(g.A, g.a_row, g.a_k, g.a_vec, m0, g.M, 0, g.K, t, va);
+  fetch_tile128(g.B, g.b_row, g.b_k, g.b_vec, n0, g.N, 0, g.K, t, vb);
+  put_tile128(g.a_row, g.a_k, g.a_vec, t, va, As[0]);
+  put_tile128(g.b_row, g.b_k, g.b_vec, t, vb, Bs[0]);
+  __syncthreads();
+  const int nk = (g.K + 15) / 16;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      fetch_tile128(g.A, g.a_row, g.a_k, g.a_vec, m0, g.M, (kt + 1) * 16, g.K, t, va);
+      fetch_tile128(g.B, g.b_row, g.b_k, g.b_vec, n0, g.N, (kt + 1) * 16, g.K, t, vb);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float a0 = As[cur][2 * s + h][wm * 64 + c], a1 = As[cur][2 * s + h][wm * 64 + 32 + c];
+      const float b0 = Bs[cur][2 * s + h][wn * 64 + c], b1 = Bs[cur][2 * s + h][wn * 64 + 32 + c];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      put_tile128(g.a_row, g.a_k, g.a_vec, t, va, As[cur ^ 1]);
+      put_tile128(g.b_row, g.b_k, g.b_vec, t, vb, Bs[cur ^ 1]);
+    }
+    __syncthreads();
+  }
+  // acc[i][j][r] = C[m0 + 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 h][n0 + 64 wn + 32 j + c]
+  if (EPI == 0 || EPI == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + c;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row >= g.M) continue;
+          float* cp = g.C + (long)row * g.ldc + col;
+          if (EPI == 1) *cp += acc[i][j][r];
+          else *cp = (g.R ? g.R[(long)row * g.ldr + col] : 0.f) + acc[i][j][r];
+        }
+      }
+  } else {
+    // SPLADE tail, as in the 64x64 kernel: rows ascend with (i, r), so sequences ascend too
+    const int col0 = n0 + wn * 64 + c, col1 = col0 + 32;
+    const bool ok0 = col0 < ta.V, ok1 = col1 < ta.V;
+    const float bias0 = ok0 ? ta.bias[col0] : 0.f, bias1 = ok1 ? ta.bias[col1] : 0.f;
+    unsigned long long best0 = 0ull, best1 = 0ull;
+    int cur = -1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool rok = row < g.M;
+        const bool live = rok && ta.mask[row] != 0;
+        const float w0 = live && ok0 ? log1pf(fmaxf(acc[i][0][r] + bias0, 0.f)) : 0.f;
+        const float w1 = live && ok1 ? log1pf(fmaxf(acc[i][1][r] + bias1, 0.f)) : 0.f;
+        const int sq = rok ? ta.seqid[row] : -1;
+        if (sq != cur) {
+          if (cur >= 0) {
+            if (ok0) atomicMax(ta.keys + (long)cur * ta.V + col0, best0);
+            if (ok1) atomicMax(ta.keys + (long)cur * ta.V + col1, best1);
+          }
+          cur = sq;
+          best0 = best1 = 0ull;
+        }
+        if (rok) {
+          const unsigned long long tag = 0xFFFFFFFFu - (uint32_t)ta.pos[row];
+          const unsigned long long k0 = ((unsigned long long)__float_as_uint(w0) << 32) | tag;
+          const unsigned long long k1 = ((unsigned long long)__float_as_uint(w1) << 32) | tag;
+          best0 = k0 > best0 ? k0 : best0;
+          best1 = k1 > best1 ? k1 : best1;
+        }
+        float mx = fmaxf(ok0 ? w0 : 0.f, ok1 ? w1 : 0.f);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (rok && c == 0) atomicMax(ta.twbits + row, __float_as_uint(mx));
+      }
+    if (cur >= 0) {
+      if (ok0) atomicMax(ta.keys + (long)cur * ta.V + col0, best0);
+      if (ok1) atomicMax(ta.keys + (long)cur * ta.V + col1, best1);
+    }
+  }
+}
+
 template <int EPI>
 int launch_gemm(GemmArgs g, const TailArgs& ta, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return SNX_E_SHAPE;
@@ -160,7 +334,11 @@ int launch_gemm(GemmArgs g, const TailArgs& ta, hipStream_t st) {
   };
   g.a_vec = vec_ok(g.A, g.a_row, g.a_k);
   g.b_vec = vec_ok(g.B, g.b_row, g.b_k);
-  hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, st, g, ta);
+  const bool small_only = getenv("SNX_F32_GEMM64") != nullptr;             // A/B and tests: the 64x64 kernel for every shape
+  if (!small_only && (long)g.M * g.N >= 128L * 128 * 256 && g.K >= 32)
+    hipLaunchKernelGGL(gemm_f32_128_kernel<EPI>, dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(256), 0, st, g, ta);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, st, g, ta);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }

@@ -66,6 +66,40 @@ def test_gemm_f32_all_operand_layouts(dev, M, N, K):
     assert float((dw.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * max(1.0, M ** 0.5 / 4)
 
 
+@pytest.mark.parametrize("M,N,K", [(4100, 1030, 70), (2048, 2304, 768), (5000, 900, 33)])
+def test_gemm_f32_128_tiles_equal_the_64_tiles_bit_for_bit(dev, M, N, K, monkeypatch):
+    """Large problems take 128x128x16 tiles with register prefetch (csrc/f32_path.hip gemm_f32_128_kernel); every output
+    element is the same k-ascending chain as in the 64x64 kernel (SNX_F32_GEMM64=1), so all three operand layouts
+    (forward NT + residual, dX NN, dW TN accumulating) must agree bit for bit, ragged edges included."""
+    import ctypes as C
+    from snx._lib import check, fn
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = torch.randn(N, K, generator=g).to(dev)
+    r = torch.randn(M, N, generator=g).to(dev)
+    dy = torch.randn(M, N, generator=g).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+
+    def run():
+        y = torch.empty(M, N, device=dev)
+        check(fn("snx_gemm_f32")(P(x), K, 1, P(w), K, 1, P(y), N, P(r), N, M, N, K, 0, st), "fwd")
+        dx = torch.empty(M, K, device=dev)
+        check(fn("snx_gemm_f32")(P(dy), N, 1, P(w), 1, K, P(dx), K, None, 0, M, K, N, 0, st), "dx")
+        dw = torch.ones(N, K, device=dev)
+        check(fn("snx_gemm_f32")(P(dy), 1, N, P(x), 1, K, P(dw), K, None, 0, N, K, M, 1, st), "dw")
+        torch.cuda.synchronize()
+        return y, dx, dw
+
+    got = run()
+    monkeypatch.setenv("SNX_F32_GEMM64", "1")
+    want = run()
+    for a, b, name in zip(got, want, ("y", "dx", "dw")):
+        assert torch.equal(a, b), name
+    ref = r.double() + x.double() @ w.double().t()
+    assert float((got[0].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * max(1.0, K ** 0.5 / 4)
+
+
 def _tiny_model(dev):
     from oracle import splade_oracle as O
     from tests.test_gpu_model import _build_model
