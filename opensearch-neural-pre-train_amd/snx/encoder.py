@@ -426,16 +426,50 @@ class EncoderRuntime:
         pairs = list(pairs)
         flat = [t for p in pairs for t in p]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.params):
-            sparse, tw = _SpladeEncodeFn.apply(self, len(pairs), lengths, *flat, *self.params)
+            # one autograd output per pass: a slice taken OUTSIDE the Function would cost its backward a zero fill of the
+            # whole [rows, V] gradient, a copy and an add per pass (three of each per micro-step, 9.6 M floats each)
+            res = _SpladeEncodeFn.apply(self, len(pairs), lengths, *flat, *self.params)
+            sparses, tw = res[:-1], res[-1]
         else:
             sparse, tw, _, _ = self.forward_many_impl(pairs, save=False, lengths=lengths)
-        out, r0, t0 = [], 0, 0
-        for ids, _ in pairs:
+            sparses, r0 = [], 0
+            for ids, _ in pairs:
+                sparses.append(sparse[r0:r0 + ids.shape[0]])
+                r0 += ids.shape[0]
+        out, t0 = [], 0
+        for (ids, _), sp in zip(pairs, sparses):
             B, S = ids.shape
-            out.append((sparse[r0:r0 + B], tw[t0:t0 + B * S].view(B, S)))
-            r0 += B
+            out.append((sp, tw[t0:t0 + B * S].view(B, S)))
             t0 += B * S
         return out
+
+
+def _gather_rows(gs, rows, vocab: int, device) -> torch.Tensor:
+    """The per-pass output gradients as ONE [sum(rows), V] fp32 tensor.  In place (no kernel) when they already are
+    consecutive row ranges of one buffer -- what snx.loss.SpladeLossFn.backward hands over --, else one concatenation;
+    a pass whose output took no part in the loss contributes zeros."""
+    gs = [g if g is None else (g if (g.dtype == torch.float32 and g.is_contiguous()) else g.to(torch.float32).contiguous())
+          for g in gs]
+    if all(g is not None for g in gs):
+        first = gs[0]
+        end = first.data_ptr() + first.numel() * 4
+        adjacent = True
+        for g in gs[1:]:
+            if g.untyped_storage().data_ptr() != first.untyped_storage().data_ptr() or g.data_ptr() != end:
+                adjacent = False
+                break
+            end += g.numel() * 4
+        if adjacent and len(gs) > 1:
+            total = sum(rows)
+            need = first.storage_offset() + total * vocab
+            if first.untyped_storage().nbytes() >= need * 4:
+                return torch.empty(0, dtype=torch.float32, device=device).set_(
+                    first.untyped_storage(), first.storage_offset(), (total, vocab), (vocab, 1))
+        if len(gs) == 1:
+            return gs[0]
+    parts = [g if g is not None else torch.zeros((b, vocab), dtype=torch.float32, device=device)
+             for g, b in zip(gs, rows)]
+    return torch.cat(parts, dim=0)
 
 
 class _SpladeEncodeFn(torch.autograd.Function):
@@ -450,11 +484,18 @@ class _SpladeEncodeFn(torch.autograd.Function):
         if rt.keep_last_ctx:
             rt.last_ctx = (saved, aux)      # parity tests: routing of the latest forward
         ctx.mark_non_differentiable(tw)
-        return sparse, tw
+        ctx.rows = [ids.shape[0] for ids, _ in pairs]
+        ctx.vocab = sparse.shape[1]
+        outs, r0 = [], 0
+        for b in ctx.rows:
+            outs.append(sparse[r0:r0 + b])
+            r0 += b
+        return tuple(outs) + (tw,)
 
     @staticmethod
-    def backward(ctx, g_sparse, _g_tw):
+    def backward(ctx, *gs):
         rt = ctx.rt
+        g_sparse = _gather_rows(gs[:-1], ctx.rows, ctx.vocab, ctx.saved_arena.device)
         grads = rt.backward_impl(ctx.saved_arena, ctx.aux, g_sparse, ctx.sync_token)
         ctx.saved_arena = None
         head = (None, None) + tuple(None for _ in range(ctx.n_in))

@@ -49,7 +49,10 @@ class SpladeLossFn(torch.autograd.Function):
     def backward(ctx, gloss, _gs):
         q, p, n, ws = ctx.saved_tensors
         g = gloss.to(torch.float32).contiguous().view(1)
-        dq, dp, dn = torch.empty_like(q), torch.empty_like(p), torch.empty_like(n)
+        # one buffer, three row ranges: when q / p / n are the outputs of ONE native pass (forward_many), its backward
+        # recognises the adjacent gradients and reads the buffer in place (snx/encoder.py _gather_rows)
+        g_all = torch.empty((q.shape[0] + p.shape[0] + n.shape[0], q.shape[1]), dtype=torch.float32, device=q.device)
+        dq, dp, dn = g_all[:q.shape[0]], g_all[q.shape[0]:q.shape[0] + p.shape[0]], g_all[q.shape[0] + p.shape[0]:]
         check(fn("snx_loss_bwd")(_p(q), _p(p), _p(n), _p(g), ctx.hp, ctx.dims, _p(ws), _p(dq), _p(dp), _p(dn),
                                  _stream()), "snx_loss_bwd")
         return dq, dp, dn, None, None, None, None, None, None
