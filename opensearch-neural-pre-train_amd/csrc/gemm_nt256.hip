@@ -41,6 +41,19 @@
 #include "gemm_epi.h"
 #include "snx.h"
 
+// diagnostics builds (wrong results; timing only): the K loop without its B / A fragment reads from LDS (the registers
+// keep whatever they held) -- how much of a LOAD segment the LDS reads are ("LDS bandwidth of the ping-pong tile")
+#ifdef SNX_NT256_NOBREAD
+#define NT256_BFRAG(dst, expr) asm volatile("" : "=v"(dst))
+#else
+#define NT256_BFRAG(dst, expr) dst = (expr)
+#endif
+#ifdef SNX_NT256_NOAREAD
+#define NT256_AFRAG(dst, expr) asm volatile("" : "=v"(dst))
+#else
+#define NT256_AFRAG(dst, expr) dst = (expr)
+#endif
+
 namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;
@@ -203,7 +216,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
         else if (EPI == EPI_ROPE && pend == 32) WAIT_VM(36);
         else WAIT_VM(20);
       } else {
+#if defined(SNX_NT256_LEAD_DIAG) && SNX_NT256_LEAD_DIAG == 1   // diagnostics builds: the steady-state wait one / two chunks
+        WAIT_VM(2);                                             // earlier than needed (how much the loop depends on its lead)
+#elif defined(SNX_NT256_LEAD_DIAG) && SNX_NT256_LEAD_DIAG == 2
+        WAIT_VM(0);
+#else
         WAIT_VM(4);
+#endif
       }
     };
     const char* ta = st + (wm * 128) * 128;                 // this wave's 128 A rows
@@ -213,9 +232,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int i = 0; i < N01; ++i) a[kk][i] = frag256(ta, i * 16 + li, kk * 4 + g);
+      for (int i = 0; i < N01; ++i) NT256_AFRAG(a[kk][i], frag256(ta, i * 16 + li, kk * 4 + g));
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn) b0[kk][jn] = frag256(tb, jn * 16 + li, kk * 4 + g);
+      for (int jn = 0; jn < 2; ++jn) NT256_BFRAG(b0[kk][jn], frag256(tb, jn * 16 + li, kk * 4 + g));
     }
     if (issue) dma(IC<0>(), off, kbytes, nst);
     wait_landed(0);
@@ -234,7 +253,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn) b1[kk][jn] = frag256(tb, 32 + jn * 16 + li, kk * 4 + g);
+      for (int jn = 0; jn < 2; ++jn) NT256_BFRAG(b1[kk][jn], frag256(tb, 32 + jn * 16 + li, kk * 4 + g));
     if (issue) dma(IC<1>(), off, kbytes, nst);
     wait_landed(1);
     BARRIER();
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < N23; ++i) a[kk][i] = frag256(ta, 64 + i * 16 + li, kk * 4 + g);
+      for (int i = 0; i < N23; ++i) NT256_AFRAG(a[kk][i], frag256(ta, 64 + i * 16 + li, kk * 4 + g));
     if (issue) dma(IC<2>(), off, kbytes, nst);
     wait_landed(2);
     BARRIER();
