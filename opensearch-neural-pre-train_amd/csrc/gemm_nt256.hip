@@ -48,6 +48,13 @@
 #else
 #define NT256_BFRAG(dst, expr) dst = (expr)
 #endif
+// diagnostics build (timing only, with SNX_NT256_NODMA): phases 0+1 and 2+3 without the two barriers between them, i.e.
+// slots of 32 MFMAs instead of 16
+#ifdef SNX_NT256_HALF_DIAG
+#define HALF_DIAG_BARRIER() do { } while (0)
+#else
+#define HALF_DIAG_BARRIER() BARRIER()
+#endif
 #ifdef SNX_NT256_NOAREAD
 #define NT256_AFRAG(dst, expr) asm volatile("" : "=v"(dst))
 #else
@@ -175,6 +182,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
   auto dma = [&](auto cc, const Off& o, int kbytes, char* stage) __attribute__((always_inline)) {
     constexpr int C = decltype(cc)::value;
     constexpr bool isA = (C == 0 || C == 3);
+#ifdef SNX_NT256_NODMA                                  // diagnostics build (wrong results): the K loop without its LDS-DMA
+    return;
+#endif
     const char* base = (const char*)(isA ? A : B) + kbytes;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
         for (int jn = 0; jn < 2; ++jn)
           acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[kk][jn], a[kk][i], acc[i][jn], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
-    BARRIER();
+    HALF_DIAG_BARRIER();
     // ---------------- phase 1: quadrant (rows 0..63, cols 32..63) ----------------
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
       for (int jn = 0; jn < 2; ++jn) NT256_BFRAG(b1[kk][jn], frag256(tb, 32 + jn * 16 + li, kk * 4 + g));
     if (issue) dma(IC<1>(), off, kbytes, nst);
     wait_landed(1);
-    BARRIER();
+    HALF_DIAG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -284,11 +294,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
         for (int jn = 0; jn < 2; ++jn)
           acc[4 + i][2 + jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[kk][jn], a[kk][i], acc[4 + i][2 + jn], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
-    BARRIER();
+    HALF_DIAG_BARRIER();
     // ---------------- phase 3: quadrant (rows 64..127, cols 0..31) ----------------
     if (issue) dma(IC<3>(), off, kbytes, nst);
     wait_landed(3);
-    BARRIER();
+    HALF_DIAG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
