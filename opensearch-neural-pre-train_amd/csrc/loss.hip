@@ -74,18 +74,44 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restri
     sp[r * LD + c] = c < cw ? p[(long)r * d.V + c0 + c] : 0.f;
   }
   __syncthreads();
-  // in-batch partial dots (operands rounded to bf16 when the reference's mm runs under autocast)
-  for (int pr = tid; pr < d.B * d.Bp; pr += 256) {
-    const int i = pr / d.Bp, j = pr % d.Bp;
-    const float* a = sq + i * LD;
-    const float* b = sp + j * LD;
-    float s = 0.f;
-    if (d.bf16_mm) {
-      for (int c = 0; c < d.CH; ++c) s += rbf(a[c]) * rbf(b[c]);
-    } else {
-      for (int c = 0; c < d.CH; ++c) s += a[c] * b[c];
+  // in-batch partial dots (operands rounded to bf16 when the reference's mm runs under autocast): a thread owns a
+  // 4 x 4 block of (anchor, positive) pairs -- 8 LDS reads per 16 products; every pair still sums its chunk in column
+  // order, so the partials are the bits of the one-pair-per-thread loop this replaces
+  {
+    const int nbj = (d.Bp + 3) >> 2, nblk = ((d.B + 3) >> 2) * nbj;
+    for (int blk = tid; blk < nblk; blk += 256) {
+      const int i0 = (blk / nbj) * 4, j0 = (blk % nbj) * 4;
+      const float* a[4];
+      const float* b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = sq + min(i0 + u, d.B - 1) * LD;
+        b[u] = sp + min(j0 + u, d.Bp - 1) * LD;
+      }
+      float acc[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.f;
+      for (int c = 0; c < d.CH; ++c) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          av[u] = d.bf16_mm ? rbf(a[u][c]) : a[u][c];
+          bv[u] = d.bf16_mm ? rbf(b[u][c]) : b[u][c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (i0 + u < d.B && j0 + v < d.Bp)
+            w.part_inb[(long)blockIdx.x * d.B * d.Bp + (long)(i0 + u) * d.Bp + j0 + v] = acc[u][v];
     }
-    w.part_inb[(long)blockIdx.x * d.B * d.Bp + pr] = s;
   }
   // q.p (own positive, fp32) for MarginMSE: positives of this rank start at row label_off
   for (int i = tid; i < d.B; i += 256) {
@@ -247,28 +273,49 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
   __syncthreads();
   const float fq = 2.f * d.lam_q / (float)d.B, fd = 2.f * d.lam_d / (float)d.B;
   const float fn = 2.f * d.lam_neg / (float)(d.B * d.k);
+  // A wave owns four output rows at a time (wave-uniform: the coefficients G come through the scalar cache) and its
+  // lanes the columns of the chunk: one LDS read feeds four rows.  Every output sums its terms in the order of the
+  // one-output-per-thread loops this replaces (same bits).
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // dq
-  for (int o = tid; o < d.B * d.CH; o += 256) {
-    const int i = o / d.CH, c = o % d.CH;
-    if (c >= cw) continue;
-    float s = 0.f;
-    const float* Gi = w.G + (long)i * d.Bp;
-    for (int j = 0; j < d.Bp; ++j) s += Gi[j] * (d.bf16_mm ? rbf(sp[j * LD + c]) : sp[j * LD + c]);
-    if (d.bf16_mm) s = rbf(s);
-    for (int kk = 0; kk < d.k; ++kk) s += w.Gh[i * d.k + kk] * n[(long)(i * d.k + kk) * d.V + c0 + c];
-    s += w.dpos[i] * sp[(d.label_off + i) * LD + c] + fq * w.mean_q[c0 + c];
-    dq[(long)i * d.V + c0 + c] = go * s;
+  for (int i0 = wave * 4; i0 < d.B; i0 += 16) {
+    for (int c = lane; c < cw; c += 64) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < d.Bp; ++j) {
+        const float pv = d.bf16_mm ? rbf(sp[j * LD + c]) : sp[j * LD + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] += w.G[(long)min(i0 + u, d.B - 1) * d.Bp + j] * pv;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u;
+        if (i >= d.B) break;
+        float r = d.bf16_mm ? rbf(s[u]) : s[u];
+        for (int kk = 0; kk < d.k; ++kk) r += w.Gh[i * d.k + kk] * n[(long)(i * d.k + kk) * d.V + c0 + c];
+        r += w.dpos[i] * sp[(d.label_off + i) * LD + c] + fq * w.mean_q[c0 + c];
+        dq[(long)i * d.V + c0 + c] = go * r;
+      }
+    }
   }
   // dp (all Bp rows: remote rows receive only the in-batch term)
-  for (int o = tid; o < d.Bp * d.CH; o += 256) {
-    const int j = o / d.CH, c = o % d.CH;
-    if (c >= cw) continue;
-    float s = 0.f;
-    for (int i = 0; i < d.B; ++i) s += w.G[(long)i * d.Bp + j] * (d.bf16_mm ? rbf(sq[i * LD + c]) : sq[i * LD + c]);
-    if (d.bf16_mm) s = rbf(s);
-    const int il = j - d.label_off;
-    if (il >= 0 && il < d.B) s += w.dpos[il] * sq[il * LD + c] + fd * w.mean_p[c0 + c];
-    dp[(long)j * d.V + c0 + c] = go * s;
+  for (int j0 = wave * 4; j0 < d.Bp; j0 += 16) {
+    for (int c = lane; c < cw; c += 64) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < d.B; ++i) {
+        const float qv = d.bf16_mm ? rbf(sq[i * LD + c]) : sq[i * LD + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] += w.G[(long)i * d.Bp + min(j0 + u, d.Bp - 1)] * qv;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j >= d.Bp) break;
+        float r = d.bf16_mm ? rbf(s[u]) : s[u];
+        const int il = j - d.label_off;
+        if (il >= 0 && il < d.B) r += w.dpos[il] * sq[il * LD + c] + fd * w.mean_p[c0 + c];
+        dp[(long)j * d.V + c0 + c] = go * r;
+      }
+    }
   }
   // dn
   for (int o = tid; o < d.B * d.k * d.CH; o += 256) {
