@@ -42,8 +42,16 @@ def setup_distributed() -> int:
     no GPU is visible (CPU plumbing tests of the host logic)."""
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if torch.cuda.is_available():
+        # SNX_DIST_BACKEND=gloo: rehearsal with more ranks than GPUs (ranks share devices, which RCCL refuses; snx.dist
+        # then stages the gradient buckets through the host) -- the returned index is the DEVICE the rank uses
+        backend = os.environ.get("SNX_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         dist.init_process_group(backend="gloo")
     return local_rank
@@ -251,7 +259,11 @@ def micro_step(model, loss_fn: SPLADELossV33, batch: dict, global_step: int, dev
         t_pos = t_pos.to(device)
     if t_neg is not None:
         t_neg = t_neg.to(device)
-    with autocast(device_type=device.type, dtype=torch.bfloat16, enabled=nb):
+    # ref:train_v33_ddp.py:337 autocasts to bf16 on cuda.  SNX_PRECISION=fp32 switches the block off: encoder AND loss
+    # then compute in fp32, which is what the reference's trainer does where its cuda autocast is inactive (its CPU runs,
+    # the source of goldens g2) -- a parity / debugging mode, not a training configuration
+    with autocast(device_type=device.type, dtype=torch.bfloat16,
+                  enabled=nb and os.environ.get("SNX_PRECISION", "auto") != "fp32"):
         if _fuse_passes(model):
             (anchor_repr, _), (positive_repr, _), (negative_repr, _) = unwrap(model).forward_many(
                 [(q_ids, q_mask), (p_ids, p_mask), (n_ids, n_mask)], lengths)

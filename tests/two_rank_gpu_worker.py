@@ -113,5 +113,108 @@ def main(rank: int, port: int, outdir: str) -> None:
     dist.destroy_process_group()
 
 
+def reference_replay(rank: int, port: int, outdir: str, world: int) -> None:
+    """The reference's OWN run, replayed on the GPU.  tests/golden/g2_train_epoch_w{1,2} were captured from the
+    reference's unmodified `train_epoch` on one / two gloo DDP ranks (tools/make_golden.py; CPU, where its cuda autocast
+    is disabled, i.e. fp32): tiny configuration, batches dealt round-robin, accumulate 4 -> 2 optimizer steps.  Here
+    `world` ranks on one MI355X run this repo's `train_epoch` under torch DDP(broadcast_buffers=False,
+    find_unused_parameters=False) -- ref:src/train/cli/train_v33_ddp.py:539-544 -- on the fp32 kernels
+    (SNX_PRECISION=fp32: the tiny geometry exists only there, and fp32 is what the golden's arithmetic was)."""
+    import numpy as np
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from torch.utils.data import DataLoader, Dataset
+    from oracle import splade_oracle as O
+    from src.model.losses import SPLADELossV33
+    from src.train.config.v33 import V33Config
+    from src.train.core import ddp_trainer as T
+    from tests.test_gpu_model import _build_model
+    os.environ["SNX_PRECISION"] = "fp32"
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(G, f"g2_train_epoch_w{world}.npz"))
+    meta = json.load(open(os.path.join(G, f"g2_train_epoch_w{world}.json")))
+    c = meta["conf"]
+    assert c["world"] == world
+    cfg = O.EncoderConfig.tiny()
+    params = O.perturb_params(O.init_params(cfg, seed=42), seed=7, scale=3.0)
+    batches = []
+    for i in range(meta["n_batches"]):
+        b = {k.split("::")[1]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith(f"b{i}::")}
+        b["num_negatives"] = 1
+        batches.append(b)
+    mine = [batches[j * world + rank] for j in range(len(batches) // world)]     # DistributedSampler(shuffle=False)
+
+    class DS(Dataset):
+        def __len__(self):
+            return len(mine)
+
+        def __getitem__(self, i):
+            return mine[i]
+
+    conf = V33Config()
+    conf.training.gradient_accumulation_steps = c["accum"]
+    conf.training.learning_rate = c["lr"]
+    conf.training.weight_decay = c["wd"]
+    conf.training.gradient_clip = c["clip"]
+    conf.training.log_every_n_steps = 1
+    model = DDP(_build_model(cfg, params, dev), device_ids=[0], broadcast_buffers=False, find_unused_parameters=False)
+    loss_fn = SPLADELossV33(lambda_q=c["lambda_q"], lambda_d=c["lambda_d"], temperature=O.LossConfig().temperature,
+                            flops_warmup_steps=c["flops_warmup_steps"], lambda_initial_ratio=c["lambda_initial_ratio"]).to(dev)
+    opt = T.build_optimizer(model, conf)
+    sch = T.build_scheduler(opt, c["warmup"], c["total_steps"])
+    losses = []
+    orig = T.micro_step
+
+    def recording(*a, **k):
+        loss, d = orig(*a, **k)
+        losses.append(float(loss))
+        return loss, d
+    T.micro_step = recording
+    try:
+        avg, gs = T.train_epoch(model, DataLoader(DS(), batch_size=None, shuffle=False), loss_fn, opt, sch, conf, 0, 0, dev)
+    finally:
+        T.micro_step = orig
+    torch.cuda.synchronize()
+    assert gs == meta["global_step"] == 2
+    rep = {"rank": rank}
+    if rank == 0:
+        want = np.asarray(z["losses"], dtype=np.float64)
+        got = np.asarray(losses, dtype=np.float64)
+        assert got.shape == want.shape, (got.shape, want.shape)
+        rel = float(np.abs(got - want).max() / np.abs(want).max())
+        assert rel <= 2e-4, f"per-micro-step losses differ from the reference's by {rel:.3g}"
+        assert abs(avg - meta["avg_loss"]) <= 2e-4 * abs(meta["avg_loss"])
+        worst_cos, frac_close, n_all = 1.0, 0, 0
+        for n, p in model.module.named_parameters():
+            ref = torch.from_numpy(np.asarray(z["p::" + n])).double()
+            upd_ref = ref - params[n].double()
+            upd = p.detach().cpu().double() - params[n].double()
+            if float(upd_ref.abs().max()) > 0:
+                cos = float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm() + 1e-30))
+                worst_cos = min(worst_cos, cos)
+                assert cos >= 0.995, f"{n}: update cosine {cos:.5f} against the reference's two-rank run"
+            frac_close += int(((p.detach().cpu().double() - ref).abs() <= 5e-5).sum())
+            n_all += ref.numel()
+        rep.update({"loss_rel_err": rel, "worst_update_cos": worst_cos, "frac_params_within_5e-5": frac_close / n_all})
+        # Adam turns a gradient whose sign is rounding noise into a full +-lr step: a small share of elements may sit a
+        # step apart; everything else must be the reference's value
+        assert frac_close / n_all >= 0.97, frac_close / n_all
+    # both ranks hold the same parameters (DDP averaged every micro-step, as the reference's reducer does)
+    for n, p in model.module.named_parameters():
+        t = p.detach().float().cpu().contiguous()
+        every = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        assert all(torch.equal(every[0], e) for e in every), n
+    dist.barrier()
+    with open(os.path.join(outdir, f"w{world}_rank{rank}.json"), "w") as f:
+        json.dump(rep, f)
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3])
+    if len(sys.argv) > 4 and sys.argv[4].startswith("reference_w"):
+        reference_replay(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4][len("reference_w"):]))
+    else:
+        main(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3])
