@@ -307,11 +307,11 @@ def test_cli_trains_with_two_ranks_on_one_gpu(dev, tmp_path, extra):
     assert all(torch.isfinite(v).all() for v in sd.values())
 
 
-@pytest.mark.parametrize("world", [1, 2])
-def test_reference_train_epoch_replayed_on_one_gpu(dev, tmp_path, world):
+@pytest.mark.parametrize("world,wrapper", [(1, "ddp"), (2, "ddp"), (2, "native")])
+def test_reference_train_epoch_replayed_on_one_gpu(dev, tmp_path, world, wrapper):
     """Rows a14 / a15 / e against the REFERENCE itself, at world size 1 and 2: goldens g2_train_epoch_w1 / _w2 (the
     reference's unmodified train_epoch on one / two gloo DDP ranks) replayed by that many ranks sharing this GPU -- this
-    repo's train_epoch, torch DDP around the model, fp32 kernels.  Per-micro-step losses of rank 0 within 2e-4, every parameter's update
+    repo's train_epoch, torch DDP around the model (or NativeDataParallel: one exchange per optimizer step), fp32 kernels.  Per-micro-step losses of rank 0 within 2e-4, every parameter's update
     after the two optimizer steps cos >= 0.995 with the reference's, >= 97 % of all elements within 5e-5, all ranks
     bit-equal.  See tests/two_rank_gpu_worker.py::reference_replay."""
     import json
@@ -324,7 +324,7 @@ def test_reference_train_epoch_replayed_on_one_gpu(dev, tmp_path, world):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, pkg, os.environ.get("PYTHONPATH", "")]),
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", REPLAY_WRAPPER=wrapper)
     for k in ("SNX_DIST_FORCE", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     procs = [subprocess.Popen([sys.executable, "-m", "tests.two_rank_gpu_worker", str(r), str(port), str(tmp_path),
@@ -345,4 +345,4 @@ def test_reference_train_epoch_replayed_on_one_gpu(dev, tmp_path, world):
     out = os.path.join(root, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_report.jsonl"), "a") as f:
-        f.write(json.dumps({"test": "reference_train_epoch_replayed", "world": world, **rep}) + "\n")
+        f.write(json.dumps({"test": "reference_train_epoch_replayed", "world": world, "wrapper": wrapper, **rep}) + "\n")

@@ -159,7 +159,12 @@ def reference_replay(rank: int, port: int, outdir: str, world: int) -> None:
     conf.training.weight_decay = c["wd"]
     conf.training.gradient_clip = c["clip"]
     conf.training.log_every_n_steps = 1
-    model = DDP(_build_model(cfg, params, dev), device_ids=[0], broadcast_buffers=False, find_unused_parameters=False)
+    if os.environ.get("REPLAY_WRAPPER", "ddp") == "native":
+        # --native-dp: gradients accumulated in the flat buffer and exchanged ONCE per optimizer step (overlapped with the
+        # window's last backward), fused clip + AdamW -- the same mathematics as the reference's per-micro-step reduction
+        model = T.NativeDataParallel(_build_model(cfg, params, dev), n_buckets=3)
+    else:
+        model = DDP(_build_model(cfg, params, dev), device_ids=[0], broadcast_buffers=False, find_unused_parameters=False)
     loss_fn = SPLADELossV33(lambda_q=c["lambda_q"], lambda_d=c["lambda_d"], temperature=O.LossConfig().temperature,
                             flops_warmup_steps=c["flops_warmup_steps"], lambda_initial_ratio=c["lambda_initial_ratio"]).to(dev)
     opt = T.build_optimizer(model, conf)
