@@ -458,6 +458,47 @@ def test_gemm_nt256_with_reserved_cus(dev, reserved):
     assert float((got.float() - x.float() @ w.float().t()).abs().max()) < 0.05
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (36864, 2304, 768), (9000, 1152, 768), (8200, 64, 64), (12345, 768, 128),
+                                   (20000, 2304, 192), (36864, 768, 2304), (4100, 320, 256), (16448, 512, 64),
+                                   (8193, 832, 1152), (10007, 1600, 320), (33333, 256, 448)])
+def test_gemm_nt256_all_epilogues_equal_the_128_kernel_bit_for_bit(dev, M, N, K):
+    """The round-3 kernel on every shape class it can meet: whole rounds only, short tiles of 64 / 128 / 192 rows, a ragged
+    last panel (M % 64 != 0), half-empty column tiles (N % 256 != 0), one K-tile (K = 64) and 36 of them, fewer tiles than
+    workgroups -- with all its epilogues (store, fp32 residual, RoPE from the table and from pre-resolved rows, GeGLU
+    forward, GeGLU backward), forced on (`snx_nt256_configure(2, ...)`), against the 128x128 kernel, which sums k in the
+    same order: every output tensor must be equal bit for bit.  (The 128x128 kernel itself is held to fp32 torch by the
+    tests above.)"""
+    from snx._lib import fn
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev).to(BF16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(BF16)
+    hin = torch.randn(M, N, generator=g).to(dev)
+    S = 256
+    tab = ops.rope_table(S, 64, 160000.0, dev)
+    pos = (torch.arange(M, dtype=torch.int32, device=dev) % S).contiguous()
+    rc = (2 * N // 3) // 64 * 64
+    rows = ops.rope_rows(tab, pos)
+    u = torch.randn(M, 2 * N, generator=g).to(dev).to(BF16)
+    calls = {"store": lambda: (ops.gemm_nt(x, w),), "resid": lambda: (ops.gemm_nt_resid(x, w, hin),)}
+    if N % 64 == 0:
+        calls["rope"] = lambda: (ops.gemm_nt_rope(x, w, tab, pos, rc, validate=False),)
+        calls["rope_rows"] = lambda: (ops.gemm_nt_rope_rows(x, w, tab, pos, rows, rc),)
+        calls["geglu_fwd"] = lambda: ops.gemm_nt_geglu_fwd(x, w)
+        calls["geglu_bwd"] = lambda: (ops.gemm_nt_geglu_bwd(x, w, u),)
+    try:
+        for name, f in calls.items():
+            fn("snx_nt256_configure")(0, 0)
+            ref = [t.clone() for t in f()]
+            fn("snx_nt256_configure")(2, 1024)
+            got = f()
+            torch.cuda.synchronize()
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b), (name, M, N, K, float((a.float() - b.float()).abs().max()))
+    finally:
+        fn("snx_nt256_configure")(1, 8192)
+
+
 @pytest.mark.parametrize("M", [8192 + 64, 8192 + 37])
 def test_gemm_tn_256_layout(dev, M):
     """Exact check of the 256x256 form: dY = a 0/1 selection pattern, so dW[n, :] = X[row(n), :] bit for bit
