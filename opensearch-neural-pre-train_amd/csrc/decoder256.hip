@@ -406,29 +406,33 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
         ent[i] = sub < nsub ? g.subtab[sub] : (i32x4){-1, 0, 0, 0};
         tok[i] = pre_tok[i];
       }
-      uint32_t best[NJ] = {0u, 0u, 0u};
+      // Keys are compared as SIGNED integers from here on: a negative logit is a negative key and loses against the
+      // initial 0, which is relu; among non-negative values the order is the unsigned one.  (One v_max_f32 per
+      // element less than clamping first; the bias goes on two rows at a time, v_pk_add_f32.)
+      int32_t best[NJ] = {0, 0, 0};
       int cur_seq = -1;
       auto flush = [&](int seq) {                     // this wave's column maxima of sequence `seq` -> key array
         if (seq < 0) return;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          uint32_t k = best[j];
-          const uint32_t o = (uint32_t)__shfl_xor((int)k, 32, 64);
+          int32_t k = best[j];
+          const int32_t o = __shfl_xor(k, 32, 64);
           k = o > k ? o : k;
           const int col = col0 + 32 * j;
-          if (hh == 0 && col < g.V && (k >> 16)) atomicMax(g.keys + (long)seq * g.V + col, k);
-          best[j] = 0u;
+          if (hh == 0 && col < g.V && (k >> 16)) atomicMax(g.keys + (long)seq * g.V + col, (uint32_t)k);   // k >= 0
+          best[j] = 0;
         }
       };
       // maximum over the 32 lanes of each half (DPP inside the rows of 16 lanes, then lane 15 of the even rows
       // into the odd rows): lanes 16-31 / 48-63 end up with it.  old = 0 is the identity of the unsigned maximum,
       // which lets the DPP moves fold into v_max_u32_dpp.
-      auto half_max = [](uint32_t x) {
-        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true));   // row_half_mirror
-        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true));   // row_mirror
-        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1, 3
+      // (row keys are non-negative: the initial 0 below is in every maximum)
+      auto half_max = [](int32_t x) {
+        x = max(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+        x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+        x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));   // row_half_mirror
+        x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));   // row_mirror
+        x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1, 3
         return x;
       };
 #pragma unroll
@@ -439,21 +443,22 @@ __global__ __launch_bounds__(256) void decoder256_kernel(DecArgs g) {
           cur_seq = ent[i][0];
         }
         const uint32_t tagbase = 0xFFFFu - (uint32_t)(ent[i][2] + 4 * hh);
-        uint32_t mine = 0u;
+        int32_t mine = 0;
 #pragma unroll
         for (int v = 0; v < 16; v += 2) {             // rows v and v + 1 of this lane: one bf16 pair per column tile
           const uint32_t tag0 = tagbase - (uint32_t)(8 * (v >> 2) + (v & 3)), tag1 = tag0 - 1u;
-          uint32_t k0[NJ], k1[NJ];
+          int32_t k0[NJ], k1[NJ];
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            const bf16x2 pk = (bf16x2){f2bf(fmaxf(acc[i][j][v] + bcol[j], 0.f)), f2bf(fmaxf(acc[i][j][v + 1] + bcol[j], 0.f))};
+            const f32x2 sum = (f32x2){acc[i][j][v], acc[i][j][v + 1]} + (f32x2){bcol[j], bcol[j]};
+            const bf16x2 pk = (bf16x2){f2bf(sum[0]), f2bf(sum[1])};
             const uint32_t w = __builtin_bit_cast(uint32_t, pk);
-            k0[j] = (w << 16) | tag0;                 // key = value bits << 16 | 0xFFFF - list position
-            k1[j] = (w & 0xFFFF0000u) | tag1;
+            k0[j] = (int32_t)((w << 16) | tag0);      // key = value bits << 16 | 0xFFFF - list position
+            k1[j] = (int32_t)((w & 0xFFFF0000u) | tag1);
             best[j] = max(best[j], max(k0[j], k1[j]));   // tag0 > tag1: the earlier row wins a tie
           }
           // a row's keys share their tag, so the row maximum of the keys is (max value bits) << 16 | tag
-          const uint32_t r0 = half_max(max(max(k0[0], k0[1]), k0[2])), r1 = half_max(max(max(k1[0], k1[1]), k1[2]));
+          const int32_t r0 = half_max(max(max(max(k0[0], k0[1]), k0[2]), 0)), r1 = half_max(max(max(max(k1[0], k1[1]), k1[2]), 0));
           mine = (lane & 15) == v ? r0 : mine;
           mine = (lane & 15) == v + 1 ? r1 : mine;
           if ((v & 6) == 6) __builtin_amdgcn_sched_barrier(0);   // bound the window: four rows' worth of temporaries
