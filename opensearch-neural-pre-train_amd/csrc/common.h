@@ -90,3 +90,13 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// one launch for the bf16 copy + transposed bf16 copy of up to 64 same-shaped fp32 matrices (elementwise.hip; used by the
+// weight-cache refresh in model.hip)
+#define SNX_CAST_BATCH_MAX 64
+struct CastBatch {
+  const float* src[SNX_CAST_BATCH_MAX];
+  bf16_t* out[SNX_CAST_BATCH_MAX];
+  bf16_t* out_t[SNX_CAST_BATCH_MAX];
+};
+int snx_cast_both_batched(const CastBatch& b, int n, int R, int C, int interleave, hipStream_t st);

@@ -67,6 +67,42 @@ __global__ void cast_interleave_kernel(const float* __restrict__ in, bf16_t* __r
     }
 }
 
+// Batched forms for the weight-cache refresh (model.hip): one launch per shape class, blockIdx.z = layer.  The cache
+// refresh of the 149 M model was 157 launches of 6-12 us each behind every optimizer step; it is 7 now.
+// INTERLEAVE = false: out[z] [R, C] = bf16(in[z]) and out_t[z] [C, R] = its transpose (R rows as given);
+// INTERLEAVE = true : Wi [2I, C] with the GeGLU row order of cast_interleave_kernel (R = 2 I).
+template <bool INTERLEAVE>
+__global__ void cast_both_batched_kernel(CastBatch b, int R, int C, int I) {
+  __shared__ float tile[64][65];
+  const float* __restrict__ in = b.src[blockIdx.z];
+  bf16_t* __restrict__ out = b.out[blockIdx.z];
+  bf16_t* __restrict__ out_t = b.out_t[blockIdx.z];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int gr = r0 + r, gc = c0 + tx;
+    const float v = (gr < R && gc < C) ? in[(long)(INTERLEAVE ? geglu_src_row(gr, I) : gr) * C + gc] : 0.f;
+    tile[r][tx] = v;
+    if (gr < R && gc < C) out[(long)gr * C + gc] = f2bf(v);
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int gc = c0 + c, gr = r0 + tx;
+    if (gc < C && gr < R) out_t[(long)gc * R + gr] = f2bf(tile[tx][c]);
+  }
+}
+
+// interleave != 0: the tensors are Wi [2 I, C] (R = 2 I, I % 32 == 0)
+int snx_cast_both_batched(const CastBatch& b, int n, int R, int C, int interleave, hipStream_t st) {
+  if (n <= 0 || n > SNX_CAST_BATCH_MAX || R <= 0 || C <= 0) return SNX_E_ARG;
+  if (interleave && ((R & 1) || ((R / 2) % 32))) return SNX_E_SHAPE;
+  const dim3 grid(cdiv(C, 64), cdiv(R, 64), n);
+  if (interleave) hipLaunchKernelGGL(cast_both_batched_kernel<true>, grid, dim3(256), 0, st, b, R, C, R / 2);
+  else hipLaunchKernelGGL(cast_both_batched_kernel<false>, grid, dim3(256), 0, st, b, R, C, 0);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
 extern "C" int snx_cast_geglu_interleave(const float* in, void* out, void* out_t, int32_t I, int32_t C,
                                          hipStream_t st) {
   if (!in || (!out && !out_t) || I <= 0 || C <= 0) return SNX_E_ARG;

@@ -4,6 +4,8 @@
 // transformers modeling_modernbert.py:434-478,522-550) or its complete backward.
 // No allocation, no host sync, caller-owned buffers, stream-ordered, graph-capturable.
 #include <vector>
+#include <cstdlib>
+
 #include "common.h"
 #include "snx.h"
 
@@ -275,6 +277,23 @@ extern "C" int snx_weight_cache_refresh(const snx_model_desc* d, const void* con
     return snx_cast_transpose_bf16((const float*)params[idx], base + ot, R, C, st);
   };
   RC(snx_cast_bf16((const float*)params[p.tok_emb()], base + c.emb, (int64_t)V * H, st));
+  const bool per_tensor = getenv("SNX_WCACHE_PER_TENSOR") != nullptr;   // A/B and tests: one launch per copy
+  if (!per_tensor && d->layers <= SNX_CAST_BATCH_MAX) {
+    // one launch per shape class (Wqkv, attn.Wo, Wi, mlp.Wo), blockIdx.z = layer: 7 launches instead of 157
+    CastBatch bq, bo, bi, bm;
+    for (int l = 0; l < d->layers; ++l) {
+      bq.src[l] = (const float*)params[p.wqkv(l)]; bq.out[l] = (bf16_t*)(base + c.wqkv[l]); bq.out_t[l] = (bf16_t*)(base + c.wqkv_t[l]);
+      bo.src[l] = (const float*)params[p.wo(l)]; bo.out[l] = (bf16_t*)(base + c.wo[l]); bo.out_t[l] = (bf16_t*)(base + c.wo_t[l]);
+      bi.src[l] = (const float*)params[p.wi(l)]; bi.out[l] = (bf16_t*)(base + c.wi[l]); bi.out_t[l] = (bf16_t*)(base + c.wi_t[l]);
+      bm.src[l] = (const float*)params[p.wo_mlp(l)]; bm.out[l] = (bf16_t*)(base + c.wom[l]); bm.out_t[l] = (bf16_t*)(base + c.wom_t[l]);
+    }
+    RC(snx_cast_both_batched(bq, d->layers, 3 * H, H, 0, st));
+    RC(snx_cast_both_batched(bo, d->layers, H, H, 0, st));
+    RC(snx_cast_both_batched(bi, d->layers, 2 * I, H, 1, st));
+    RC(snx_cast_both_batched(bm, d->layers, H, I, 0, st));
+    RC(both(p.head_dense(), c.dense, c.dense_t, H, H));
+    return SNX_OK;
+  }
   for (int l = 0; l < d->layers; ++l) {
     RC(both(p.wqkv(l), c.wqkv[l], c.wqkv_t[l], 3 * H, H));
     RC(both(p.wo(l), c.wo[l], c.wo_t[l], H, H));

@@ -313,6 +313,26 @@ def test_full_size_vs_reference_golden_g3(dev, full_setup):
     model.zero_grad(set_to_none=True)
 
 
+def test_weight_cache_batched_refresh_equals_per_tensor(dev, full_setup, monkeypatch):
+    """The bf16 weight cache (natural + transposed copies, Wi in the GeGLU row order) is rebuilt behind every optimizer
+    step: one launch per shape class with the layer in blockIdx.z (7 launches) must write the bytes of the 157
+    per-tensor launches it replaces (SNX_WCACHE_PER_TENSOR=1)."""
+    import ctypes as C
+    from snx._lib import check, fn
+    cfg, params, model = full_setup
+    rt = model.runtime
+    ptrs = rt._param_ptrs()
+    nbytes = fn("snx_weight_cache_bytes")(C.byref(rt._desc))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device=dev)
+    b = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device=dev)
+    check(fn("snx_weight_cache_refresh")(C.byref(rt._desc), ptrs, C.c_void_p(a.data_ptr()), st), "batched")
+    monkeypatch.setenv("SNX_WCACHE_PER_TENSOR", "1")
+    check(fn("snx_weight_cache_refresh")(C.byref(rt._desc), ptrs, C.c_void_p(b.data_ptr()), st), "per tensor")
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
 def test_inference_matches_training_forward(dev, full_setup):
     from oracle import splade_oracle as O
     cfg, params, model = full_setup
