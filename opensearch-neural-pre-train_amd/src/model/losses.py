@@ -69,7 +69,9 @@ class SPLADELossV33(nn.Module):
                                tpos=teacher_pos_scores if use_mm else None,
                                tneg=teacher_neg_scores if use_mm else None,
                                label_off=int(kwargs.get("label_offset", 0)), bf16_mm=bf16_mm)
-        zero = sc.new_zeros(())
+        zero = getattr(self, "_zero", None)               # one cached 0-d zero per device (no fill kernel per call)
+        if zero is None or zero.device != sc.device:
+            zero = self._zero = sc.new_zeros(())
         kd_loss = zero
         if self.lambda_kd > 0 and teacher_scores is not None:   # inactive in the V33 trainer
             off = int(kwargs.get("label_offset", 0))
@@ -79,7 +81,7 @@ class SPLADELossV33(nn.Module):
             loss = loss + self.lambda_kd * kd_loss
         with torch.no_grad():
             nz = sc[6:8]
-            self._ema = 0.1 * nz if self._ema is None else 0.9 * self._ema + 0.1 * nz
+            self._ema = 0.1 * nz if self._ema is None else torch.add(0.9 * self._ema, nz, alpha=0.1)
             self._count += 1
         loss_dict = {
             "infonce": sc[1], "flops_q": sc[2], "flops_d": sc[3], "flops_neg": sc[4],
