@@ -83,28 +83,10 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long s_ro
   }
 }
 
+// epilogue of a 64x64 tile whose wave (wm, wn) holds acc (shared by the two 64x64 kernels)
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, TailArgs ta) {
-  __shared__ __attribute__((aligned(16))) float As[16][TP];
-  __shared__ __attribute__((aligned(16))) float Bs[16][TP];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int k0 = 0; k0 < g.K; k0 += 16) {
-    load_tile(g.A, g.a_row, g.a_k, g.a_vec, m0, g.M, k0, g.K, As, t);
-    load_tile(g.B, g.b_row, g.b_k, g.b_vec, n0, g.N, k0, g.K, Bs, t);
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const float a = As[2 * s + (lane >> 5)][wm * 32 + (lane & 31)];
-      const float b = Bs[2 * s + (lane >> 5)][wn * 32 + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    __syncthreads();
-  }
+__device__ __forceinline__ void gemm_f32_epilogue(const GemmArgs& g, const TailArgs& ta, const f32x16& acc, int m0, int n0, int wm,
+                                                  int wn, int lane) {
   // acc[r] = C[m0 + 32 wm + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n0 + 32 wn + (lane & 31)]
   const int col = n0 + wn * 32 + (lane & 31);
   const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
@@ -149,6 +131,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, TailArgs ta) 
     }
     if (cur >= 0 && cok) atomicMax(ta.keys + (long)cur * ta.V + col, best);
   }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, TailArgs ta) {
+  __shared__ __attribute__((aligned(16))) float As[16][TP];
+  __shared__ __attribute__((aligned(16))) float Bs[16][TP];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < g.K; k0 += 16) {
+    load_tile(g.A, g.a_row, g.a_k, g.a_vec, m0, g.M, k0, g.K, As, t);
+    load_tile(g.B, g.b_row, g.b_k, g.b_vec, n0, g.N, k0, g.K, Bs, t);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float a = As[2 * s + (lane >> 5)][wm * 32 + (lane & 31)];
+      const float b = Bs[2 * s + (lane >> 5)][wn * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  gemm_f32_epilogue<EPI>(g, ta, acc, m0, n0, wm, wn, lane);
 }
 
 // The same contraction on 128x128x16 tiles for the large problems (the 149 M model's Linears and its decoder at
@@ -325,6 +332,100 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g, TailAr
   }
 }
 
+// The 64x64 tile with a 64-deep K-step and the next step's operands prefetched into registers: for SMALL problems (a
+// query batch of 64 tokens is one row of 36 tiles), where the kernel above is a chain of K / 16 exposed memory round
+// trips on a few dozen workgroups -- 60 us per Linear, 5.3 of the 6.6 ms of a single-query forward.  Same k-ascending
+// chain per output element: identical bits.
+__device__ __forceinline__ void fetch_tile64x64(const float* __restrict__ P, long s_row, long s_k, int vec, int row0, int nrows,
+                                                int k0, int K, int t, float (&v)[16]) {
+  if (vec && s_k == 1) {                                        // k contiguous: one row, 16 consecutive k per thread
+    const int r = t >> 2, kk = (t & 3) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (row0 + r < nrows && k0 + kk + 4 * q + 3 < K) {
+        const f32x4 x = *(const f32x4*)(P + (long)(row0 + r) * s_row + k0 + kk + 4 * q);
+        v[4 * q] = x[0]; v[4 * q + 1] = x[1]; v[4 * q + 2] = x[2]; v[4 * q + 3] = x[3];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[4 * q + u] = (row0 + r < nrows && k0 + kk + 4 * q + u < K) ? P[(long)(row0 + r) * s_row + k0 + kk + 4 * q + u] : 0.f;
+      }
+    }
+  } else if (vec && s_row == 1) {                               // rows contiguous: k rows kk + 16 q, 4 rows each
+    const int r = (t & 15) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = (t >> 4) + 16 * q;
+      if (k0 + kk < K && row0 + r + 3 < nrows) {
+        const f32x4 x = *(const f32x4*)(P + (long)(k0 + kk) * s_k + row0 + r);
+        v[4 * q] = x[0]; v[4 * q + 1] = x[1]; v[4 * q + 2] = x[2]; v[4 * q + 3] = x[3];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[4 * q + u] = (k0 + kk < K && row0 + r + u < nrows) ? P[(long)(k0 + kk) * s_k + row0 + r + u] : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = t + i * 256, r = idx & 63, kk = idx >> 6;
+      v[i] = (row0 + r < nrows && k0 + kk < K) ? P[(long)(row0 + r) * s_row + (long)(k0 + kk) * s_k] : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void put_tile64x64(long s_row, long s_k, int vec, int t, const float (&v)[16], float (*S)[TP]) {
+  if (vec && s_k == 1) {
+    const int r = t >> 2, kk = (t & 3) * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S[kk + i][r] = v[i];
+  } else if (vec && s_row == 1) {
+    const int r = (t & 15) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = (t >> 4) + 16 * q;
+      *(f32x4*)&S[kk][r] = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = t + i * 256;
+      S[idx >> 6][idx & 63] = v[i];
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_deepk_kernel(GemmArgs g, TailArgs ta) {
+  __shared__ __attribute__((aligned(16))) float As[64][TP];
+  __shared__ __attribute__((aligned(16))) float Bs[64][TP];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float va[16], vb[16];
+  fetch_tile64x64(g.A, g.a_row, g.a_k, g.a_vec, m0, g.M, 0, g.K, t, va);
+  fetch_tile64x64(g.B, g.b_row, g.b_k, g.b_vec, n0, g.N, 0, g.K, t, vb);
+  for (int k0 = 0; k0 < g.K; k0 += 64) {
+    put_tile64x64(g.a_row, g.a_k, g.a_vec, t, va, As);
+    put_tile64x64(g.b_row, g.b_k, g.b_vec, t, vb, Bs);
+    __syncthreads();
+    if (k0 + 64 < g.K) {                                // the next step's operands fly under this step's 32 MFMAs
+      fetch_tile64x64(g.A, g.a_row, g.a_k, g.a_vec, m0, g.M, k0 + 64, g.K, t, va);
+      fetch_tile64x64(g.B, g.b_row, g.b_k, g.b_vec, n0, g.N, k0 + 64, g.K, t, vb);
+    }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const float a = As[2 * s + (lane >> 5)][wm * 32 + (lane & 31)];
+      const float b = Bs[2 * s + (lane >> 5)][wn * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  gemm_f32_epilogue<EPI>(g, ta, acc, m0, n0, wm, wn, lane);
+}
+
 template <int EPI>
 int launch_gemm(GemmArgs g, const TailArgs& ta, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return SNX_E_SHAPE;
@@ -339,6 +440,8 @@ int launch_gemm(GemmArgs g, const TailArgs& ta, hipStream_t st) {
   const bool small_only = getenv("SNX_F32_GEMM64") != nullptr;             // A/B and tests: the 64x64 kernel for every shape
   if (!small_only && (long)g.M * g.N >= 128L * 128 * 256 && g.K >= 32)
     hipLaunchKernelGGL(gemm_f32_128_kernel<EPI>, dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(256), 0, st, g, ta);
+  else if (!small_only && g.K >= 128 && (long)cdiv(g.M, 64) * cdiv(g.N, 64) <= 512)   // few tiles: latency-bound
+    hipLaunchKernelGGL(gemm_f32_deepk_kernel<EPI>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, st, g, ta);
   else
     hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, st, g, ta);
   SNX_CHECK_LAUNCH();

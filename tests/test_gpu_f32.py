@@ -66,11 +66,13 @@ def test_gemm_f32_all_operand_layouts(dev, M, N, K):
     assert float((dw.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * max(1.0, M ** 0.5 / 4)
 
 
-@pytest.mark.parametrize("M,N,K", [(4100, 1030, 70), (2048, 2304, 768), (5000, 900, 33)])
+@pytest.mark.parametrize("M,N,K", [(4100, 1030, 70), (2048, 2304, 768), (5000, 900, 33),
+                                   (64, 2304, 768), (100, 300, 200), (1000, 768, 1152), (33, 1000, 130)])
 def test_gemm_f32_128_tiles_equal_the_64_tiles_bit_for_bit(dev, M, N, K, monkeypatch):
-    """Large problems take 128x128x16 tiles with register prefetch (csrc/f32_path.hip gemm_f32_128_kernel); every output
-    element is the same k-ascending chain as in the 64x64 kernel (SNX_F32_GEMM64=1), so all three operand layouts
-    (forward NT + residual, dX NN, dW TN accumulating) must agree bit for bit, ragged edges included."""
+    """Large problems take 128x128x16 tiles with register prefetch (csrc/f32_path.hip gemm_f32_128_kernel), small ones
+    (the last four shapes: a query batch) the 64x64 tile with a 64-deep prefetched K-step (gemm_f32_deepk_kernel); every
+    output element is the same k-ascending chain as in the plain 64x64x16 kernel (SNX_F32_GEMM64=1), so all three operand
+    layouts (forward NT + residual, dX NN, dW TN accumulating) must agree bit for bit, ragged edges included."""
     import ctypes as C
     from snx._lib import check, fn
     g = torch.Generator().manual_seed(M + N + K)
