@@ -313,6 +313,47 @@ def test_full_size_vs_reference_golden_g3(dev, full_setup):
     model.zero_grad(set_to_none=True)
 
 
+def test_other_geometry_wider_model(dev):
+    """Nothing in the kernels is specialised to the 149 M model's widths beyond head_dim 64, hidden % 256 and
+    intermediate % 128 (`EncoderGeometry.bf16_unsupported_reason`; ModernBERT-large's 2,624 is not, its fp32 path runs):
+    a wider model -- hidden 1,024, 16 heads, intermediate 2,560, local window 128; three layers and a small vocabulary
+    here to keep the CPU oracle quick -- through the bf16 kernels against the oracle's emulated-bf16 forward,
+    the fp32 path against the oracle's fp32 forward, and a backward through both that leaves finite gradients of the
+    right scale."""
+    from oracle import splade_oracle as O
+    from tests.helpers import sparse_ulp_stats
+    cfg = O.EncoderConfig(vocab_size=2000, hidden_size=1024, intermediate_size=2560, num_hidden_layers=3,
+                          num_attention_heads=16, local_attention=128, pad_token_id=1999)
+    params = O.perturb_params(O.init_params(cfg, seed=21), seed=22, scale=2.0, bias_mean=-0.1)
+    gen = torch.Generator().manual_seed(5)
+    B, S = 3, 200
+    ids = torch.randint(5, 1990, (B, S), generator=gen)
+    mask = torch.ones(B, S, dtype=torch.int64)
+    mask[1, 150:] = 0
+    mask[2, 77:] = 0
+    ids[mask == 0] = cfg.pad_token_id
+    model = _build_model(cfg, params, dev)
+    want16, _ = O.splade_forward(params, cfg, ids, mask, "bf16")
+    want32, _ = O.splade_forward(params, cfg, ids, mask, "fp32")
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        got16, _ = model(ids.to(dev), mask.to(dev))
+    # (1,024 inputs per decoder row and weights perturbed to twice the spread: the logit noise of section 2's model is
+    # ~1.5x that of the 149 M fixtures, hence the wider 6-sigma floor and looser shares than assert_ulp_statement's)
+    st = sparse_ulp_stats(got16, want16, logit_abs_tol=2.5e-2)
+    assert st["far"] == 0 and st["ulp0"] >= 0.5 and st["ulp2"] + st["floor"] <= 0.06, st
+    assert st["mean_abs"] <= 3e-3 and st["max_abs"] <= 2e-2 and abs(st["bias"]) <= 4e-4, st
+    got32, _ = model(ids.to(dev), mask.to(dev))                  # outside autocast: the fp32 path
+    err32 = float((got32.detach().cpu() - want32).abs().max())
+    assert err32 <= 2e-5 * max(1.0, float(want32.abs().max())), err32
+    _report("wider_model_h1024_i2560", {"bf16": st, "fp32_max_abs": err32})
+    for out in (got16, got32):
+        model.zero_grad(set_to_none=True)
+        out.square().sum().backward()
+        gn = {n: float(p.grad.float().norm()) for n, p in model.named_parameters()}
+        assert all(v == v and v < 1e12 for v in gn.values()), gn
+        assert gn["model.model.layers.0.attn.Wqkv.weight"] > 0 and gn["model.model.embeddings.tok_embeddings.weight"] > 0
+
+
 def test_weight_cache_batched_refresh_equals_per_tensor(dev, full_setup, monkeypatch):
     """The bf16 weight cache (natural + transposed copies, Wi in the GeGLU row order) is rebuilt behind every optimizer
     step: one launch per shape class with the layer in blockIdx.z (7 launches) must write the bytes of the 157
