@@ -252,6 +252,10 @@ int snx_geglu_bwd(const void* u, const void* dy, void* du, int32_t T, int32_t I,
 int snx_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse, int32_t T,
                  int32_t nseq, int32_t max_seqlen, int32_t heads, int32_t head_dim, int32_t window,
                  hipStream_t stream);
+/* Process-wide choice of the backward for sequence groups of <= 256 tokens: 1 (default) the one-pass kernel
+ * (csrc/attention_1p.hip: every score formed once, dQ / dK / dV from one launch), 0 the dQ + dK/dV kernel pair
+ * (csrc/attention_unit.hip; the second opinion of the parity tests).  Longer groups always stream tile by tile. */
+int snx_attn_configure(int32_t bwd_onepass);
 /* _ex: `groups` [host] = {n, (seq_begin, nseq, max_len) x n}, n <= 8, consecutive sequence groups with their own
  * maximum length (NULL: one group of max_seqlen) -- only sizes the launch, results are identical. */
 int snx_attn_fwd_ex(const void* qkv, const int32_t* cu_seqlens, const int64_t* mask, void* out, float* lse,

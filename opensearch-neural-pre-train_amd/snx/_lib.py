@@ -39,6 +39,7 @@ SIGNATURES = {
     "snx_attn_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_attn_fwd_ex": (I32, [P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_attn_bwd_ex": (I32, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
+    "snx_attn_configure": (I32, [I32]),
     "snx_gemm_nt_rope": (I32, [P, P, P, P, P, I32, I32, I32, I32, P]),
     "snx_rope_rows": (I32, [P, P, P, I32, P]),
     "snx_gemm_nt_rope_rows": (I32, [P, P, P, P, P, P, I32, I32, I32, I32, P]),

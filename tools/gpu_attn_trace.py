@@ -20,7 +20,7 @@ mask = torch.ones(T, dtype=torch.int64, device=dev)
 qkv = torch.randn(T, 3 * heads * 64, device=dev).to(torch.bfloat16)
 dout = torch.randn(T, heads * 64, device=dev).to(torch.bfloat16)
 L = lib()
-fset = L.snx_attn_trace_set
+fset = L.snx_attn1p_trace_set
 fset.restype = C.c_int
 fset.argtypes = [C.c_void_p]
 for w in (-1, 64):
@@ -28,15 +28,17 @@ for w in (-1, 64):
     for _ in range(3):
         ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False)
     nb = 128 * heads
-    buf = torch.zeros(nb * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(nb * 16, dtype=torch.int64, device=dev)
     fset(buf.data_ptr())
     ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False)
     torch.cuda.synchronize()
     fset(0)
-    b = buf.view(nb, 8).cpu()
-    t0, t1, t2, t3, r0, r1 = (b[:, i].double() for i in (0, 1, 2, 3, 4, 5))
-    live = t2 > 0
-    med = lambda x: float(x[live].median())   # noqa: E731
-    print(f"window={w}: load {med(t1 - t0):.0f} cyc, row group 1 {med(t2 - t1):.0f} cyc, row group 2 {med(t3 - t2):.0f} cyc, "
-          f"workgroup wall {med((r1 - r0) * 10):.0f} ns; kernel span {(float(r1.max() - r0.min()) * 10) / 1e3:.1f} us "
+    b = buf.view(nb, 16).cpu().double()
+    med = lambda x: float(x.median())   # noqa: E731
+    names = ["prologue", "s0 top+barrier", "s0 phase 1", "s0 barrier", "s0 phase 2", "s1 top+barrier", "s1 phase 1",
+             "s1 barrier", "s1 phase 2"]
+    parts = ", ".join(f"{n} {med(b[:, i + 1] - b[:, i]):.0f}" for i, n in enumerate(names))
+    print(f"window={w} (cycles, wave 0, median over workgroups): {parts}; loop {med(b[:, 10] - b[:, 1]):.0f}, "
+          f"epilogue {med(b[:, 11] - b[:, 10]):.0f}, whole {med(b[:, 11] - b[:, 0]):.0f}; workgroup wall "
+          f"{med((b[:, 13] - b[:, 12]) * 10):.0f} ns; kernel span {float(b[:, 13].max() - b[:, 12].min()) * 10 / 1e3:.1f} us "
           f"for {nb} workgroups", flush=True)
