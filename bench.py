@@ -72,17 +72,18 @@ def make_batches(n, B, Sq, Sd, k, vocab, pad, seed, dev, teacher=False):
     return out
 
 
-def cpu_baseline(seconds_budget: float = 30.0):
+def cpu_baseline(seconds_budget: float = 30.0, cores: int | None = None):
     """The oracle (CPU restatement of the reference step, fp32, torch CPU threads = host cores given
     to this process) on a bounded sample: B=4 triplets per micro-step, q64/d256 full length."""
     from oracle import splade_oracle as O
-    # The GPU box gives one GPU's job a 16-core share of the host (more threads than that oversubscribe it: with every
-    # core the scheduler reports, the 30-second sample took minutes); the host's own core counts are recorded beside it.
+    # The GPU box gives one GPU's job a 16-core share of the host: the default sample runs on 16 threads.  `cores`
+    # (--cpu-baseline-only --cpu-cores N | all) times the same sample on any thread count; the all-physical-cores run of
+    # SURVEY 8(d) is kept under profiles/ (r04_cpu_baseline_cores.json) beside the 16-thread one.
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(16, avail))
+    cores = max(1, min(16, avail)) if cores is None else max(1, cores)
     torch.set_num_threads(cores)
     try:
         import psutil
@@ -121,7 +122,8 @@ PMC_KERNELS = {
     "gemm_tn_accum": ["gemm_tn256_kernel", "gemm_tn_kernel"],
     "decoder_splade_fwd": ["decoder256_kernel", "decoder_splade_kernel"],
     "attn_fwd": ["attn_fwd_unit_kernel", "attn_fwd_kernel"],
-    "attn_bwd": ["attn_bwd_dq_unit_kernel", "attn_bwd_dkv_unit_kernel", "attn_bwd_dq_kernel", "attn_bwd_dk"],
+    "attn_bwd": ["attn_bwd_1p_kernel", "attn_bwd_dq_unit_kernel", "attn_bwd_dkv_unit_kernel", "attn_bwd_dq_kernel",
+                 "attn_bwd_dk"],
 }
 
 
@@ -137,7 +139,7 @@ def kernel_source_hash() -> str:
     return h.hexdigest()
 
 
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
 
 
 def pmc_traffic(cls: str):
@@ -180,11 +182,52 @@ def main():
     ap.add_argument("--cross-gpu-negatives", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-item-sync-leg", action="store_true",
+                    help="skip the extra leg that times the reference's literal loop (three forwards + loss.item())")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="time the CPU oracle sample and exit (no GPU)")
+    ap.add_argument("--cpu-cores", default=None, help="threads of the CPU sample: a number, or 'all' (physical cores)")
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:
+        n = None
+        if args.cpu_cores == "all":
+            try:
+                import psutil
+                n = psutil.cpu_count(logical=False)
+            except Exception:
+                n = os.cpu_count()
+        elif args.cpu_cores:
+            n = int(args.cpu_cores)
+        t0 = time.time()
+        rec = cpu_baseline(cores=n)
+        rec["wall_s_of_the_sample"] = time.time() - t0
+        print(json.dumps(rec))
+        return
+
+    # N > 1 without a launcher: this process becomes the launcher.  It starts N fresh workers through
+    # torch.distributed.run BEFORE making any GPU call of its own (counting devices is not one) and exits with their
+    # code; a line that says n_gpus 1 can therefore never come out of a --gpus N invocation.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        import socket
+        import subprocess
+        ndev = torch.cuda.device_count()
+        if os.environ.get("SNX_BENCH_BACKEND", "nccl") == "nccl" and ndev < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible; one process per GPU over RCCL")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] --gpus {args.gpus} without RANK: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N), or plain "
+                         "`python bench.py --gpus N`, which starts them itself")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # SNX_BENCH_BACKEND=gloo: REHEARSAL of the N > 1 launch line on fewer GPUs than ranks (ranks share devices, the
@@ -207,8 +250,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     from snx._lib import fn
     from src.model.losses import SPLADELossV33
@@ -230,17 +271,21 @@ def main():
     optimizer = T.build_optimizer(wrapped, config)
     scheduler = T.build_scheduler(optimizer, 100, 10000)
     B, Sq, Sd, k = args.batch, args.q_len, args.d_len, args.negatives
-    n_batches = min(args.steps + args.warmup, 8)
+    n_batches = min(args.steps + args.warmup, 32)   # pre-staged device batches; a timed micro-step never waits for the host
     batches = make_batches(n_batches, B, Sq, Sd, k, model.vocab_size, model.config.pad_token_id, 42 + rank, dev,
                            teacher=args.margin_mse > 0)
     xneg = args.cross_gpu_negatives
-    state = {"i": 0, "gs": 0}
+    state = {"i": 0, "gs": 0, "sync": False, "last": 0.0}
 
     def one_step():
         b = batches[state["i"] % n_batches]
+        if state["sync"]:
+            os.environ["SNX_FUSED_PASSES"] = "0"
         loss, _ = T.micro_step(wrapped, loss_fn, b, state["gs"], dev, args.accum, xneg,
                                last_of_window=(state["i"] + 1) % args.accum == 0)
         state["i"] += 1
+        if state["sync"]:
+            state["last"] = loss.item()                    # ref:train_v33_ddp.py:444, one host sync per micro-step
         if state["i"] % args.accum == 0:
             T.optimizer_step(wrapped, optimizer, scheduler, config)
             state["gs"] += 1
@@ -277,7 +322,7 @@ def main():
                                f"AdamW+clip every {args.accum} micro-steps"
                                + (", MarginMSE 0.5 with synthetic teacher scores" if args.margin_mse > 0 else "")
                                + (", cross-GPU in-batch negatives" if xneg else "")
-                               + "; 8 pre-staged device batches cycled through ddp_trainer.micro_step / "
+                               + f"; {n_batches} pre-staged device batches cycled through ddp_trainer.micro_step / "
                                  "optimizer_step (the body of train_epoch); no per-micro-step loss.item() "
                                  "(ref:train_v33_ddp.py:444 has one): the loss stays on the device",
                    "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": final_loss},
@@ -322,6 +367,37 @@ def main():
         for _ in range(args.accum):     # keep collectives matched with rank 0's profiled steps
             one_step()
         torch.cuda.synchronize()
+
+    # ---- the reference's literal loop: model(q); model(p); model(n) and one loss.item() per micro-step ----
+    if not args.no_item_sync_leg:
+        fused_before = os.environ.get("SNX_FUSED_PASSES")
+        state["sync"] = True
+        while state["i"] % args.accum:                 # start on a window boundary
+            one_step()
+        for _ in range(args.accum):
+            one_step()
+        barrier()
+        ksync = max(args.accum, min(args.steps, 4 * args.accum))
+        t0 = time.perf_counter()
+        for _ in range(ksync):
+            one_step()
+        barrier()
+        dts = time.perf_counter() - t0
+        state["sync"] = False
+        if fused_before is None:
+            os.environ.pop("SNX_FUSED_PASSES", None)
+        else:
+            os.environ["SNX_FUSED_PASSES"] = fused_before
+        if use_pg:
+            tmax = torch.tensor([dts], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dts = float(tmax.item())
+        result["extra"] = {"value_with_item_sync": ksync * B * world / dts, "ms_per_step": 1000.0 * dts / ksync,
+                           "steps": ksync,
+                           "note": "the reference's call pattern unchanged (ref:train_v33_ddp.py:339-343,444): three "
+                                   "separate forwards per micro-step (SNX_FUSED_PASSES=0) and loss.item() after "
+                                   "every backward; `value` above runs the three batches as one native pass and "
+                                   "keeps the loss on the device"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()

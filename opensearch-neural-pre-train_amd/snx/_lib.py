@@ -100,7 +100,19 @@ def lib():
                 "`python opensearch-neural-pre-train_amd/snx/build.py` (or __graft_entry__.build()). "
                 "There is no CPU fallback for the product path.")
         _lib = C.CDLL(LIB_PATH)
+        _configure(_lib)
     return _lib
+
+
+def _configure(L):
+    """Process-wide choices of the library, made HERE through its `snx_*_configure` entry points (include/snx.h) -- the
+    library itself reads no environment.  SNX_ATTN_BWD_ONEPASS=0: the two-pass attention backward (A/B, second opinion)."""
+    v = os.environ.get("SNX_ATTN_BWD_ONEPASS")
+    if v is not None:
+        L.snx_attn_configure.restype = C.c_int
+        L.snx_attn_configure.argtypes = [C.c_int32]
+        if L.snx_attn_configure(int(v)) != 0:
+            raise SnxLibraryError(f"SNX_ATTN_BWD_ONEPASS={v!r}: expected 0 or 1")
 
 
 _bound = {}

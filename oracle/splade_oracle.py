@@ -164,12 +164,23 @@ def _r(x: torch.Tensor, mode: str) -> torch.Tensor:
     return x.to(BF16) if mode == "bf16" else x
 
 
+# Test hook (tests/test_oracle_ulp_floor.py): a torch.Generator seed.  When set, every bf16-mode Linear sums its
+# contraction index in a permuted order -- the same products, another fp32 summation order, i.e. a SECOND correct bf16
+# implementation of the reference's arithmetic, which is what the ULP / gate-flip tolerances of the GPU parity tests
+# have to allow for.
+CONTRACTION_PERM_SEED: Optional[int] = None
+
+
 def _linear(x: torch.Tensor, w: torch.Tensor, mode: str, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """nn.Linear under autocast: bf16 operands, fp32 accumulate, bf16 result (bias added in
     fp32 before the single rounding)."""
     if mode == "fp32":
         return F.linear(x, w, bias)
-    y = x.to(BF16).float() @ w.to(BF16).float().t()
+    if CONTRACTION_PERM_SEED is not None:
+        perm = torch.randperm(w.shape[1], generator=torch.Generator().manual_seed(CONTRACTION_PERM_SEED + w.shape[1]))
+        y = x.to(BF16).float()[..., perm] @ w.to(BF16).float()[:, perm].t()
+    else:
+        y = x.to(BF16).float() @ w.to(BF16).float().t()
     if bias is not None:
         y = y + bias.to(BF16).float()
     return y.to(BF16)

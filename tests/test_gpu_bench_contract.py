@@ -33,6 +33,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert 100.0 < d["value"] < 1e5
     assert math.isfinite(d["config"]["final_loss"])
     assert "no per-micro-step loss.item()" in d["config"]["workload"]
+    ex = d["extra"]                                       # the reference's literal loop: three forwards + loss.item()
+    assert 100.0 < ex["value_with_item_sync"] <= d["value"] * 1.05 and ex["steps"] >= 4
     assert roof["traffic_provenance"]["status"].split(":")[0] in ("current", "stale", "absent")
     assert (roof["traffic"] is None) == (roof["traffic_provenance"]["status"] != "current")
 
@@ -77,3 +79,27 @@ def test_bench_launch_line_with_two_ranks_rehearsed_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert math.isfinite(d["config"]["final_loss"]) and d["value"] > 0
     assert "cpu_baseline" not in d                       # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_bench_gpus_n_without_a_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no RANK in the environment: the process must become the launcher (fresh workers
+    through torch.distributed.run, the parent never touches the GPU) -- never print an n_gpus 1 line.  On the one GPU of a
+    test box the two ranks share the device (SNX_BENCH_BACKEND=gloo); with the default backend the same invocation is
+    refused before anything starts, because one process per GPU over RCCL needs two GPUs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SNX_DIST_FORCE")}
+    env.update(SNX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "4",
+                        "--no-cpu-baseline", "--no-profile", "--no-item-sync-leg"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2"
+    import torch
+    if torch.cuda.device_count() < 2:
+        env.pop("SNX_BENCH_BACKEND")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4"],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0 and '"n_gpus"' not in r.stdout and "GPU(s) visible" in r.stderr

@@ -168,9 +168,16 @@ def test_three_backward_micro_step_exchanges_once_after_the_last_backward(dev, n
             cov = sorted(reds)
             assert cov[0][0] == 0 and cov[-1][1] == total and all(a[1] == b[0] for a, b in zip(cov, cov[1:])), cov
             del ev
+    # Parameters after the two Adam steps (lr 1e-3): an element moves by at most lr per step, so two runs differ by at most
+    # 2 steps x 2 lr; the MEAN difference is Adam sign noise on elements whose gradient is near zero -- the two runs sum the
+    # weight gradients in different orders (other token counts per launch, float atomics).  Measured on one MI355X over four
+    # batch seeds (profiles/r04_three_backward_noise.txt, tools/gpu_three_backward_noise.py): worst tensor 3.9e-6 .. 3.7e-5
+    # with either attention backward, and up to 6e-6 between two runs of the SAME configuration; 1e-4 = 0.1 lr bounds that
+    # distribution with margin while a slice reduced twice or not at all (what this test is for) moves whole tensors by
+    # ~lr and fails the coverage assertions above as well.
     for n in p_fused:
         d = (p_fused[n] - p_three[n]).abs()
-        assert float(d.max()) <= 2 * 2 * 1e-3 * 1.01 and float(d.mean()) < 0.03 * 1e-3, (n, float(d.max()), float(d.mean()))
+        assert float(d.max()) <= 2 * 2 * 1e-3 * 1.01 and float(d.mean()) < 0.1 * 1e-3, (n, float(d.max()), float(d.mean()))
 
 
 def test_bucket_plan_covers_every_unit(dev):

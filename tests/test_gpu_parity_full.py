@@ -83,6 +83,8 @@ def _run_oracle(cfg, params, b, lkw, step, k, rows):
     loss, d = O.loss_v33(lc, pinned["query"], pinned["positive"], n3, step, b.get("teacher_pos_scores"),
                          b.get("teacher_neg_scores"), "bf16")
     loss.backward()
+    for tag in ("query", "positive", "negative"):          # the values whose relu gate the oracle's gradient went through
+        free[tag + "_pinned"] = pinned[tag].detach()
     return free, loss, d, {n: l.grad for n, l in leaves.items()}
 
 
@@ -109,12 +111,26 @@ def _check_against_oracle(name, model, outs, tws, loss, d, free, oloss, od, ogra
     assert float(loss) == pytest.approx(float(oloss), rel=2e-3)
     for key in ("infonce", "flops_q", "flops_d", "flops_neg", "margin_mse"):
         assert float(d[key]) == pytest.approx(od[key], rel=2e-3, abs=2e-3), (key, float(d[key]), od[key])
-    # rel-L2 <= 2e-2 -- 3e-2 for decoder.bias: its gradient is the plain sum of the routed coefficients
-    # g / (1 + x) [x > 0], and an entry whose logit lies within the bf16 noise of zero (sigma ~2e-3 absolute)
-    # has its relu gate open in one implementation and shut in the other, i.e. contributes its whole g or nothing.
-    # With MarginMSE-sized g that alone is 1.4-2.1e-2 of the norm (measured over rounds 2-3: 1.45e-2, 2.05e-2, 2.06e-2
-    # as 1-ulp details of the RoPE rounding changed); the matrices average it away over their 768 columns.
-    bad = {n_: v for n_, v in stats.items() if v[0] < 0.999 or v[1] > (3e-2 if n_ == "model.decoder.bias" else 2e-2)}
+    # rel-L2 <= 2e-2 for every tensor.  decoder.bias is held to it on the vocabulary ids AWAY FROM THE RELU GATE: its gradient
+    # is the plain sum of the routed coefficients g / (1 + x) [x > 0], and an entry whose logit lies within the bf16 noise
+    # of zero (sigma ~2e-3 absolute) has its gate open in one implementation and shut in the other, i.e.
+    # contributes its whole g or nothing.  tests/test_oracle_ulp_floor.py measures it on the CPU between two correct bf16
+    # evaluations of the ORACLE (same products, another fp32 summation order, pinned routing): rel-L2 4.0e-2 over all ids,
+    # 1.1e-2 without the ~0.2 % of ids that own a routed logit within 6 sigma of zero -- so no bound on the unmasked tensor
+    # below that floor means anything (rounds 2-3 measured 1.45e-2 .. 2.06e-2 and round 3 raised the bound to 3e-2 after a
+    # red run: replaced by this).  The matrices average the effect away over their 768 columns and stay unmasked.
+    gate = float(np.log1p(6 * 2e-3))
+    near = torch.zeros(outs["query"].shape[-1], dtype=torch.bool)
+    for tag in ("query", "positive", "negative"):
+        a, o = outs[tag].detach().float().cpu(), free[tag + "_pinned"].float()
+        near |= ((torch.maximum(a, o) > 0) & (torch.minimum(a, o) <= gate)).any(dim=0)
+    keep = ~near
+    gb = dict(model.named_parameters())["model.decoder.bias"].grad.detach().cpu()[keep]
+    ob = ograds["model.decoder.bias"][keep]
+    stats["model.decoder.bias"] = _grad_stats(gb, ob)
+    rep["decoder_bias"] = {"ids_near_the_gate": int(near.sum()), "kept_cos_rel": list(stats["model.decoder.bias"])}
+    assert int(near.sum()) <= 0.02 * near.numel(), int(near.sum())          # the mask stays a small minority of the ids
+    bad = {n_: v for n_, v in stats.items() if v[0] < 0.999 or v[1] > 2e-2}
     assert not bad, bad
     return rep
 

@@ -390,3 +390,20 @@ def test_world_size_2_collectives_gloo():
     ret = mgr.dict()
     mp.spawn(_dist_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: (True,) * 6, 1: (True,) * 6}
+
+
+def test_bench_never_prints_a_one_gpu_line_for_a_multi_gpu_request():
+    """bench.py --gpus N (N > 1): without RANK it must launch N workers itself or fail; with a launcher whose WORLD_SIZE
+    differs from N it must fail.  Both refusals happen before any GPU call, so they are checked here without one."""
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SNX_BENCH_BACKEND")}
+    env["HIP_VISIBLE_DEVICES"] = ""                      # no GPU of its own, whatever the host has
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout and "GPU(s) visible" in r.stderr
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout and "WORLD_SIZE=1" in r.stderr
