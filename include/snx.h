@@ -221,6 +221,9 @@ int snx_gemm_tn_accum_group(const snx_tn_problem* probs /*[host]*/, int32_t npro
  * workgroups run an overlapped gradient exchange (the role of DDP's reducer, ref:src/train/cli/train_v33_ddp.py:539-544)
  * a 256-workgroup launch would run its last workgroups as a second wave, so it launches 256 - n instead (its
  * schedule balances any count).  Results are unchanged up to fp32 summation order. */
+/* The SNX_EXTRA_HIPCC_FLAGS the library was compiled with ("" for the product build); snx/_lib.py refuses a library
+ * built with a timing-only diagnostics macro (wrong results by design) unless SNX_ALLOW_DIAG_LIB=1. */
+const char* snx_build_flags(void);
 int snx_set_reserved_cus(int32_t n);
 int snx_get_reserved_cus(void);
 

@@ -40,6 +40,7 @@ SIGNATURES = {
     "snx_attn_fwd_ex": (I32, [P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_attn_bwd_ex": (I32, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_attn_configure": (I32, [I32]),
+    "snx_build_flags": (C.c_char_p, []),
     "snx_gemm_nt_rope": (I32, [P, P, P, P, P, I32, I32, I32, I32, P]),
     "snx_rope_rows": (I32, [P, P, P, I32, P]),
     "snx_gemm_nt_rope_rows": (I32, [P, P, P, P, P, P, I32, I32, I32, I32, P]),
@@ -100,8 +101,29 @@ def lib():
                 "`python opensearch-neural-pre-train_amd/snx/build.py` (or __graft_entry__.build()). "
                 "There is no CPU fallback for the product path.")
         _lib = C.CDLL(LIB_PATH)
+        _check_build_flags(_lib)
         _configure(_lib)
     return _lib
+
+
+def _check_build_flags(L):
+    """A library compiled with a timing-only diagnostics macro returns WRONG results by design (snx/build.py
+    WRONG_RESULT_MACROS): refuse it as the product library unless the caller says it knows (SNX_ALLOW_DIAG_LIB=1, the
+    microbenchmark tools); trace builds compute the same results and only warn."""
+    try:
+        L.snx_build_flags.restype = C.c_char_p
+        flags = (L.snx_build_flags() or b"").decode()
+    except AttributeError:
+        return
+    if not flags:
+        return
+    from snx.build import WRONG_RESULT_MACROS
+    bad = [m for m in WRONG_RESULT_MACROS if m in flags]
+    if bad and os.environ.get("SNX_ALLOW_DIAG_LIB", "0") != "1":
+        raise SnxLibraryError(f"{LIB_PATH} was built with {flags!r}: {', '.join(bad)} make its results wrong (timing-only "
+                              "diagnostics). Rebuild without SNX_EXTRA_HIPCC_FLAGS, or set SNX_ALLOW_DIAG_LIB=1.")
+    import warnings
+    warnings.warn(f"libsnx.so is a diagnostics build ({flags})")
 
 
 def _configure(L):

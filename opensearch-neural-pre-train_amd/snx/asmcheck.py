@@ -1,8 +1,9 @@
 """Build-time guard for the kernels that read LDS through volatile inline asm.
 
-The persistent kernels (csrc/gemm_tn256.hip, csrc/decoder256.hip, csrc/gemm_nt256.hip) issue their fragment reads
-as ``asm volatile("ds_read_...")`` so that hipcc's waitcnt pass does not drain the LDS-DMA ring in front of every
-read.  The price: the compiler does not know that the destination registers are not valid until the
+The persistent kernels csrc/gemm_tn256.hip and csrc/decoder256.hip issue their fragment reads as
+``asm volatile("ds_read_...")`` so that hipcc's waitcnt pass does not drain the LDS-DMA ring in front of every
+read (csrc/gemm_nt256.hip reads its fragments through plain C++ loads, which hipcc tracks itself: it is guarded for
+the zero-scratch rule, and the scan finds nothing to object to there).  The price: the compiler does not know that the destination registers are not valid until the
 ``s_waitcnt lgkmcnt`` the SOURCE places behind them.  If register pressure makes it spill or copy such a register
 (``v_accvgpr_write``, ``scratch_store``, ``v_mov``) between the read and that wait, the copy is taken before the data
 has arrived and the kernel returns intermittently wrong rows -- seen in round 2 on builds with different flags.
@@ -63,6 +64,9 @@ def kernels_of(asm: str) -> Dict[str, List[str]]:
             continue
         if cur is None:
             continue
+        if m:                                # a local label: kept, so that the scan can follow back-edges
+            out[cur].append(m.group(1) + ":")
+            continue
         s = line.split(";", 1)[0].strip()
         if s.startswith(".end_amdhsa_kernel") or s.startswith(".section") or s.startswith(".Lfunc_end"):
             if s.startswith(".Lfunc_end") or s.startswith(".section"):
@@ -74,12 +78,17 @@ def kernels_of(asm: str) -> Dict[str, List[str]]:
     return out
 
 
-def scan_kernel(lines: Iterable[str]) -> List[str]:
-    """Violations: 'instruction <- ds_read' pairs where a pending LDS-read destination is touched too early."""
-    pending: List[Tuple[set, str]] = []      # in issue order: (destination registers, the read)
-    smem = 0                                 # scalar loads outstanding (share lgkmcnt, may return out of order)
-    bad: List[str] = []
-    for ins in lines:
+def _scan(lines: List[str], start: int, stop: int, pending: List[Tuple[set, str]], smem: int, bad: List[str],
+          labels: Dict[str, int], follow: bool) -> None:
+    """Linear scan of lines[start:stop] from the state (pending, smem).  With `follow`, every BACKWARD branch (loop
+    back-edge) met with reads still pending re-scans its loop body once from the branch's state: a read issued at the
+    bottom of a loop whose retiring wait sits at the loop top is then seen by a copy or spill on the back-edge path."""
+    i = start
+    while i < stop:
+        ins = lines[i]
+        i += 1
+        if ins.endswith(":"):
+            continue
         op = ins.split()[0]
         if op == "s_waitcnt":
             m = _LGKM.search(ins)
@@ -94,6 +103,11 @@ def scan_kernel(lines: Iterable[str]) -> List[str]:
         if op.startswith("s_load") or op.startswith("s_buffer_load"):
             smem += 1
             continue
+        if follow and pending and (op.startswith("s_cbranch") or op == "s_branch"):
+            tgt = labels.get(ins.split()[-1])
+            if tgt is not None and tgt < i:
+                _scan(lines, tgt, i - 1, list(pending), smem, bad, labels, False)
+            continue
         touched = _regs(ins.split(None, 1)[1]) if " " in ins else set()
         if pending and touched:
             for dst, rd in pending:
@@ -103,7 +117,18 @@ def scan_kernel(lines: Iterable[str]) -> List[str]:
         if op.startswith("ds_read") or op.startswith("ds_load"):
             ops = ins.split(None, 1)[1]
             pending.append((_regs(ops.split(",")[0]), ins))
-    return bad
+
+
+def scan_kernel(lines: Iterable[str]) -> List[str]:
+    """Violations: 'instruction <- ds_read' pairs where a pending LDS-read destination is touched too early.  The scan is
+    linear in text order (forward branches: the fall-through path and the taken path both lie ahead in the text, so a
+    read pending at the branch stays pending at the target) plus one pass over every loop body entered through its
+    back-edge; it does not enumerate paths through nested or irreducible control flow."""
+    lines = list(lines)
+    labels = {ln[:-1]: i for i, ln in enumerate(lines) if ln.endswith(":")}
+    bad: List[str] = []
+    _scan(lines, 0, len(lines), [], 0, bad, labels, True)
+    return list(dict.fromkeys(bad))
 
 
 def check_asm(asm: str, names: Iterable[str], where: str = "", allow_scratch: bool = False) -> Dict[str, dict]:

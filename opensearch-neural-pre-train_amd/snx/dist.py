@@ -42,11 +42,24 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+_staging_logged = False
+
+
 def rccl() -> bool:
-    """True when the default group is RCCL (backend string "nccl").  Device tensors under any other backend (gloo:
+    """True when the default group can move CUDA tensors through RCCL: backend "nccl", or a composite such as
+    "cpu:gloo,cuda:nccl" (what a plain `init_process_group()` creates).  Device tensors under any other backend (gloo:
     `tests/test_gpu_dist.py` runs two ranks on ONE GPU that way, which RCCL refuses) are exchanged through host
-    copies made on the exchange stream -- same ordering, no device collectives."""
-    return dist.get_backend() == "nccl"
+    copies made on the exchange stream -- same ordering, no device collectives; that choice is logged once, because it
+    is correct but an order of magnitude slower than the collective."""
+    global _staging_logged
+    ok = "nccl" in str(dist.get_backend()).lower()
+    if not ok and not _staging_logged and torch.cuda.is_available():
+        _staging_logged = True
+        import logging
+        logging.getLogger(__name__).warning(
+            "snx.dist: process group backend %r has no RCCL for device tensors; gradient buckets and gathered "
+            "positives are staged through host memory (rehearsal mode)", dist.get_backend())
+    return ok
 
 
 def allreduce_flat_grads(flat: torch.Tensor, bucket_mb: int = 0) -> None:
@@ -120,8 +133,12 @@ class BucketedGradSync:
         self.slices: List[Tuple[int, int]] = []          # what the last armed backward reduced (tests)
         self.log: List[tuple] = []                       # ("fwd"|"bwd"|"exchange"|"reduce", ...) call order (tests)
         self.keep_log = os.environ.get("SNX_GRAD_SYNC_LOG", "0") == "1"
-        # CUs the persistent weight-gradient kernel leaves to RCCL's channel workgroups while the exchange overlaps
-        # the backward (include/snx.h snx_set_reserved_cus); 0 = none
+        # CUs the persistent GEMM kernels (one workgroup per CU) leave to RCCL's channel workgroups while the exchange
+        # overlaps the backward (include/snx.h snx_set_reserved_cus); 0 = none.  The default 32 is UNMEASURED (no
+        # multi-GPU node was available in rounds 1-4): it costs the armed backward -- one micro-step in `accum` -- up to
+        # 12.5 % of its GEMM rate, against the alternative that a 256-workgroup launch finds a few CUs held by RCCL for
+        # the whole bucket and runs its last workgroups as a second wave (2x for that launch).  A/B on a node:
+        # SNX_EXCHANGE_RESERVED_CUS=0 / 16 / 32.
         self.reserved_cus = int(os.environ.get("SNX_EXCHANGE_RESERVED_CUS", "32"))
 
     def _note(self, *ev) -> None:

@@ -36,6 +36,13 @@ def test_scanner_on_hand_written_streams():
     # overwriting a pending destination is as bad as reading it
     waw = ["ds_read_b128 v[12:15], v0", "v_mov_b32 v14, 0", "s_waitcnt lgkmcnt(0)"]
     assert len(A.scan_kernel(waw)) == 1
+    # a read at the bottom of a loop whose wait sits at the loop top: the copy on the back-edge path is found
+    loop = [".LBB0_1:", "s_waitcnt lgkmcnt(0)", "v_mov_b32 v1, v12", "v_accvgpr_write_b32 a9, v13", "ds_read_b128 v[12:15], v0",
+            "s_cbranch_scc1 .LBB0_1"]
+    assert A.scan_kernel(loop) == []
+    loop_bad = [".LBB0_1:", "v_accvgpr_write_b32 a9, v13", "s_waitcnt lgkmcnt(0)", "ds_read_b128 v[12:15], v0",
+                "s_cbranch_scc1 .LBB0_1"]
+    assert len(A.scan_kernel(loop_bad)) == 1
     # the read's own address register may be reused at once
     addr = ["ds_read_b128 v[12:15], v0", "v_add_u32 v0, 64, v0", "s_waitcnt lgkmcnt(0)"]
     assert A.scan_kernel(addr) == []
