@@ -221,6 +221,15 @@ int snx_gemm_tn_accum_group(const snx_tn_problem* probs /*[host]*/, int32_t npro
  * workgroups run an overlapped gradient exchange (the role of DDP's reducer, ref:src/train/cli/train_v33_ddp.py:539-544)
  * a 256-workgroup launch would run its last workgroups as a second wave, so it launches 256 - n instead (its
  * schedule balances any count).  Results are unchanged up to fp32 summation order. */
+/* Process-wide switches of the library (csrc/config.h).  The library reads no environment variable; the Python binding
+ * maps its SNX_* variables onto these keys once, at load time (snx/_lib.py), tests and tools call them directly.
+ * Keys (default): nt256 (1; 0 off, 2 every eligible shape), nt256_min_m (8192), tn256 (1), tn256_min_m (8192),
+ * dec256 (1), dec256_min_t (2048), bwd_overlap (1), side_prio (1), attn_streaming (0), attn_bwd_onepass (1),
+ * splade_dh_panels (16), f32_gemm64 (0), f32_attn_rows (0), wcache_per_tensor (0); diagnostics builds (-DSNX_DIAG) add
+ * gemm_cg, gemm_dbg, gemm_mid, tn_splits, nt256_cg, nt256_dbg, nt256_force, tn256_tail_pct, tn256_dbg.  Unknown key or
+ * value out of range: SNX_E_ARG. */
+int snx_configure(const char* key, int32_t value);
+int snx_config_get(const char* key, int32_t* value);
 /* The SNX_EXTRA_HIPCC_FLAGS the library was compiled with ("" for the product build); snx/_lib.py refuses a library
  * built with a timing-only diagnostics macro (wrong results by design) unless SNX_ALLOW_DIAG_LIB=1. */
 const char* snx_build_flags(void);

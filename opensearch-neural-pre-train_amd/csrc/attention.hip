@@ -15,6 +15,7 @@
 // second product is a permutation of the key index (lane group g, element j <-> key
 // 16*(2c + j/4) + 4g + j%4); both operands use the same permutation.
 #include "attention_common.h"
+#include "config.h"
 #include "snx.h"
 
 // Block schedule (speed only).  Blocks b and b+8 share an XCD and its L2.  The unit of placement is
@@ -280,10 +281,7 @@ int attn_unit_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, cons
                   const int32_t* cu_seqlens, const int64_t* mask, bf16_t* dqkv, const f32x2* rope_tab,
                   const int32_t* pos, int T, int heads, int window, const int32_t* groups, hipStream_t st);
 
-static bool attn_streaming_only() {
-  static const bool v = getenv("SNX_ATTN_STREAMING") != nullptr;   // A/B switch: force the tiled kernels
-  return v;
-}
+static bool attn_streaming_only() { return g_snx_cfg.attn_streaming != 0; }   // A/B switch: force the tiled kernels
 
 // Validates the group table, then calls resident(sub-table of the groups of <= 256 tokens) once and
 // streaming(seq_begin, nseq, max_len) for every longer group.

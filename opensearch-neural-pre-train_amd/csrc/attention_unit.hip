@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "attention_common.h"
+#include "config.h"
 #include "snx.h"
 
 namespace {
@@ -527,17 +528,12 @@ int attn_bwd_onepass(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, c
                      const int32_t* pos, int T, int heads, int window, const int32_t* groups, hipStream_t st);
 
 // 1 (default): the one-pass kernel of attention_1p.hip; 0: the dQ + dK/dV pair below (A/B and second opinion in tests)
-static int g_attn_bwd_onepass = 1;
-extern "C" int snx_attn_configure(int32_t bwd_onepass) {
-  if (bwd_onepass != 0 && bwd_onepass != 1) return SNX_E_ARG;
-  g_attn_bwd_onepass = bwd_onepass;
-  return SNX_OK;
-}
+extern "C" int snx_attn_configure(int32_t bwd_onepass) { return snx_configure("attn_bwd_onepass", bwd_onepass); }
 
 int attn_unit_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta,
                   const int32_t* cu_seqlens, const int64_t* mask, bf16_t* dqkv, const f32x2* rope_tab,
                   const int32_t* pos, int T, int heads, int window, const int32_t* groups, hipStream_t st) {
-  if (g_attn_bwd_onepass)
+  if (g_snx_cfg.attn_bwd_onepass)
     return attn_bwd_onepass(qkv, out, dout, lse, cu_seqlens, mask, dqkv, rope_tab, pos, T, heads, window, groups, st);
   UnitSched sc;
   int blocks;

@@ -1,0 +1,41 @@
+// Process-wide configuration of libsnx.so.  The library reads NO environment variable: every choice below is made through
+// `snx_configure(key, value)` (include/snx.h) -- by the Python binding from its own SNX_* variables at load time
+// (snx/_lib.py), by tests and tools directly.  The second block exists in diagnostics builds only (-DSNX_DIAG): those
+// switches change which kernel variant or schedule a concluded experiment used; the product build compiles their
+// defaults in.
+#pragma once
+
+struct SnxConfig {
+  int nt256 = 1;              // 256x256 persistent NT GEMM: 0 off, 1 default shape policy, 2 every eligible shape
+  int nt256_min_m = 8192;     //   ... from this many rows on
+  int tn256 = 1;              // 256x256 persistent weight-gradient GEMM (0: the 128x128 kernel everywhere)
+  int tn256_min_m = 8192;
+  int dec256 = 1;             // 256x192 persistent decoder + SPLADE kernel (0: the 128x128 kernel)
+  int dec256_min_t = 2048;
+  int bwd_overlap = 1;        // weight-gradient GEMMs of the backward on the internal side stream
+  int side_prio = 1;          //   ... which has the lowest stream priority
+  int attn_streaming = 0;     // 1: tile-by-tile attention kernels for every sequence length
+  int attn_bwd_onepass = 1;   // one-pass attention backward for sequences of <= 256 tokens (0: dQ + dK/dV pair)
+  int splade_dh_panels = 16;  // vocabulary panels of the routed decoder backward's dHd gather (0: one wave per row)
+  int f32_gemm64 = 0;         // fp32 path: the 64x64 GEMM tile for every shape
+  int f32_attn_rows = 0;      // fp32 path: wave-per-(token, head) attention forward
+  int wcache_per_tensor = 0;  // bf16 weight cache refreshed one launch per tensor
+#ifdef SNX_DIAG
+  int gemm_cg = -1;           // column-group width of the 128x128 NT tile order (-1: cost model)
+  int gemm_dbg = 0;           // 1: L2-resident operands, 2: no epilogue
+  int gemm_mid = (1 << 1) | (1 << 4);   // epilogues (bitmask over EPI) on the mid-step-barrier main loop
+  int tn_splits = 0;          // token splits of the 128x128 weight-gradient GEMM (0: fill model)
+  int nt256_cg = -1;
+  int nt256_dbg = 0;          // 1 no write-back, 2 L2-resident operands, 4 write-back without stores, 16 no deep request
+  int nt256_force = 0;        // epilogues (bitmask) that take every eligible shape
+  int tn256_tail_pct = 95;
+  int tn256_dbg = 0;          // 1 no atomics, 2 no DMA, 4 L2-resident operands
+#endif
+};
+extern SnxConfig g_snx_cfg;
+
+#ifdef SNX_DIAG
+#define SNX_DIAG_CFG(field, dflt) (g_snx_cfg.field)
+#else
+#define SNX_DIAG_CFG(field, dflt) (dflt)
+#endif

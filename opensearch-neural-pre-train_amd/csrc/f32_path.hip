@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "config.h"
 #include "snx.h"
 
 namespace {
@@ -437,7 +438,7 @@ int launch_gemm(GemmArgs g, const TailArgs& ta, hipStream_t st) {
   };
   g.a_vec = vec_ok(g.A, g.a_row, g.a_k);
   g.b_vec = vec_ok(g.B, g.b_row, g.b_k);
-  const bool small_only = getenv("SNX_F32_GEMM64") != nullptr;             // A/B and tests: the 64x64 kernel for every shape
+  const bool small_only = g_snx_cfg.f32_gemm64 != 0;             // A/B and tests: the 64x64 kernel for every shape
   if (!small_only && (long)g.M * g.N >= 128L * 128 * 256 && g.K >= 32)
     hipLaunchKernelGGL(gemm_f32_128_kernel<EPI>, dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(256), 0, st, g, ta);
   else if (!small_only && g.K >= 128 && (long)cdiv(g.M, 64) * cdiv(g.N, 64) <= 512)   // few tiles: latency-bound
@@ -1016,7 +1017,7 @@ extern "C" int snx_model_forward_f32(const snx_model_desc* d, const void* const*
     RC(linear_fwd(B(s.x_attn[l]), F(p.wqkv(l)), nullptr, B(s.qkv[l]), T, 3 * H, H, st));
     const long nrope = (long)T * 2 * d->heads * (hd / 2);
     LAUNCH1D(rope_f32_kernel, nrope, B(s.qkv[l]), (const f32x2*)(global ? rope_global : rope_local), pos, nrope, d->heads, hd, 0);
-    if (hd % 8 == 0 && !getenv("SNX_F32_ATTN_ROWS")) {
+    if (hd % 8 == 0 && !g_snx_cfg.f32_attn_rows) {
       const int zq = max(1, min(64, cdiv(cdiv(T, nseq), AQ)));
       hipLaunchKernelGGL(attn_f32_fwd_tiled_kernel, dim3(nseq, d->heads, zq), dim3(256), 0, st, B(s.qkv[l]), cu_seqlens, mask,
                          B(s.attn[l]), B(s.lse[l]), T, d->heads, hd, global ? -1 : d->window, scale);

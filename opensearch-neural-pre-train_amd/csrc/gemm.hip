@@ -19,6 +19,7 @@
 // 4-stage ring (571), persistent workgroups with cross-tile prefetch (neutral), stream-K for dW.
 // Two independent 4-wave workgroups per CU with one barrier per 64-deep K-step win.
 #include "gemm_core.h"
+#include "config.h"
 #include "gemm_epi.h"
 #include "gemm_tn.h"
 #include "snx.h"
@@ -267,8 +268,8 @@ static int launch_nt(const void* A, const void* B, int M, int N, int K, const Ep
   // column-group width of the tile order (gemm_core.h): keep an XCD's share of the weight matrix (cg tiles of
   // BN x K bf16) within ~1.8 MB of its L2 unless re-reading the activation panels ceil(tn / cg) times costs more
   // than letting the weights spill (estimate: spilled weights are re-fetched ~4x per XCD).
-  static const int cg_env = getenv("SNX_GEMM_CG") ? atoi(getenv("SNX_GEMM_CG")) : -1;
-  static const int dbg = getenv("SNX_GEMM_DBG") ? atoi(getenv("SNX_GEMM_DBG")) : 0;
+  const int cg_env = SNX_DIAG_CFG(gemm_cg, -1);
+  const int dbg = SNX_DIAG_CFG(gemm_dbg, 0);
   int cg = tn;
   if (cg_env > 0) cg = cg_env < tn ? cg_env : tn;
   else if (cg_env < 0) {
@@ -283,9 +284,8 @@ static int launch_nt(const void* A, const void* B, int M, int N, int K, const Ep
   }
   TileOrder order{tm, tn, cdiv(tm, 8), cg};
   // MID: mid-step barrier main loop (gemm_core.h) -- measured faster for the epilogues that also stream a second
-  // operand (residual, saved u), slower for the plain long-K shapes.  SNX_GEMM_MID=<bitmask over EPI> overrides.
-  static const int mid_mask = getenv("SNX_GEMM_MID") ? atoi(getenv("SNX_GEMM_MID"))
-                                                     : ((1 << EPI_RESID_F32) | (1 << EPI_GEGLU_BWD));
+  // operand (residual, saved u), slower for the plain long-K shapes (diagnostics builds: "gemm_mid" = bitmask over EPI).
+  const int mid_mask = SNX_DIAG_CFG(gemm_mid, (1 << EPI_RESID_F32) | (1 << EPI_GEGLU_BWD));
   if ((mid_mask >> EPI) & 1) {
     auto kern = gemm_nt_kernel<BM, BN, 2, 2, EPI, true>;
     hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(Core::NTHREADS), Core::LDS_BYTES, st, (const bf16_t*)A,
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnGroup grp, int M, int
 // CUs) are what counts; among the split counts that keep >= 256 tokens per workgroup pick the best-filled one,
 // preferring fewer splits (less float-atomic traffic) when the fill is within 2 %.
 static int tn_pick_splits(int tiles, int M) {
-  static const int forced = getenv("SNX_TN_SPLITS") ? atoi(getenv("SNX_TN_SPLITS")) : 0;
+  const int forced = SNX_DIAG_CFG(tn_splits, 0);
   const int max_splits = cdiv(M, 256) < 1 ? 1 : cdiv(M, 256);
   if (forced > 0) return forced < max_splits ? forced : max_splits;
   int best = 1;
@@ -481,9 +481,8 @@ static int tn_pick_splits(int tiles, int M) {
 }
 
 static int launch_tn_group(const TnGroup& g, int M, hipStream_t st) {
-  // long token ranges: the 256x256 persistent form (gemm_tn256.hip); SNX_TN256=0 keeps the 128x128 kernel
-  static const int tn256 = getenv("SNX_TN256") ? atoi(getenv("SNX_TN256")) : 1;
-  static const int tn256_min_m = getenv("SNX_TN256_MIN_M") ? atoi(getenv("SNX_TN256_MIN_M")) : 8192;
+  // long token ranges: the 256x256 persistent form (gemm_tn256.hip); "tn256" = 0 keeps the 128x128 kernel
+  const int tn256 = g_snx_cfg.tn256, tn256_min_m = g_snx_cfg.tn256_min_m;
   if (tn256 && M >= tn256_min_m) {
     // whole 64-row K-steps there; a ragged rest of the token range (< 64 rows) comes back to this kernel
     const int M64 = M & ~63;

@@ -38,6 +38,7 @@
 // row-major, 16 B per lane = full 128-byte lines.  The stores stay in flight into the next tile: its first two
 // LOAD segments wait with vmcnt(4 + stores) (the vm queue retires in order).
 #include "gemm_core.h"
+#include "config.h"
 #include "gemm_epi.h"
 #include "snx.h"
 
@@ -570,8 +571,8 @@ static int launch(const void* A, const void* B, int M, int N, int K, const EpiAr
   const int tm = cdiv(M, BM), tn = cdiv(N, BN);
   // column-group width of the tile order: an XCD's share of B (cg tiles of 256 x K bf16) should stay in its 4 MiB L2
   // beside the streaming A panels and outputs; re-reading the A panels ceil(tn / cg) times is the price
-  static const int cg_env = getenv("SNX_NT256_CG") ? atoi(getenv("SNX_NT256_CG")) : -1;
-  static const int dbg = getenv("SNX_NT256_DBG") ? atoi(getenv("SNX_NT256_DBG")) : 0;
+  const int cg_env = SNX_DIAG_CFG(nt256_cg, -1);
+  const int dbg = SNX_DIAG_CFG(nt256_dbg, 0);
   int cg = tn;
   if (cg_env > 0) cg = cg_env < tn ? cg_env : tn;
   else if (cg_env < 0) {
@@ -610,18 +611,15 @@ static int launch(const void* A, const void* B, int M, int N, int K, const EpiAr
 
 // Shapes this form takes: enough rows to give every workgroup work, N % 64 == 0 (16-byte row-major write-back in
 // whole 64-column wave spans), K % 64 == 0, operand byte offsets within 32 bits.
-static int g_nt256_on = -1, g_nt256_min_m = -1;
-// A/B and test switch (also env SNX_NT256 / SNX_NT256_MIN_M, read once): on = 0 keeps every shape on the 128x128 kernel
+// A/B and test switch (= snx_configure "nt256" / "nt256_min_m"): on = 0 keeps every shape on the 128x128 kernel
 extern "C" int snx_nt256_configure(int32_t on, int32_t min_m) {
-  g_nt256_on = on;                                     // 0 = off, 1 = default shape policy, 2 = every eligible shape
-  if (min_m > 0) g_nt256_min_m = min_m;
-  return SNX_OK;
+  const int rc = snx_configure("nt256", on);           // 0 = off, 1 = default shape policy, 2 = every eligible shape
+  if (rc != SNX_OK) return rc;
+  return min_m > 0 ? snx_configure("nt256_min_m", min_m) : SNX_OK;
 }
 
 int snx_launch_nt256(int epi, const void* A, const void* B, int M, int N, int K, const EpiArgs& e, hipStream_t st) {
-  if (g_nt256_on < 0) g_nt256_on = getenv("SNX_NT256") ? atoi(getenv("SNX_NT256")) != 0 : 1;
-  if (g_nt256_min_m < 0) g_nt256_min_m = getenv("SNX_NT256_MIN_M") ? atoi(getenv("SNX_NT256_MIN_M")) : 8192;
-  const int on = g_nt256_on, min_m = g_nt256_min_m;
+  const int on = g_snx_cfg.nt256, min_m = g_snx_cfg.nt256_min_m;
   // Which shapes come here by default (measured at 36,864 rows against the 128x128 kernel, tools/gpu_nt256.py):
   // wide outputs (>= 6 column tiles: ~20 units per workgroup, short tiles are a small share) with the RoPE and
   // GeGLU-forward epilogues, and the plain store from three column tiles on (N = 768: 6.75 units per workgroup, one
@@ -629,8 +627,8 @@ int snx_launch_nt256(int epi, const void* A, const void* B, int M, int N, int K,
   // 128x128 kernel in the microbenchmark, 0.5 ms per micro-step faster inside the training step, where operands
   // come cold).  The two epilogues that stream a second operand (residual, GeGLU backward) gain nothing from the
   // exposed write-back (bench with SNX_NT256_FORCE=2 / 16: -0.2 / -0.4 ms the wrong way).
-  // SNX_NT256_FORCE=<bitmask over EPI>: take every eligible shape of those epilogues (A/B runs).
-  static const int force = getenv("SNX_NT256_FORCE") ? atoi(getenv("SNX_NT256_FORCE")) : 0;
+  // diagnostics builds, "nt256_force" = <bitmask over EPI>: take every eligible shape of those epilogues (A/B runs).
+  const int force = SNX_DIAG_CFG(nt256_force, 0);
   const bool dflt = ((epi == EPI_ROPE || epi == EPI_GEGLU_FWD) && N >= 6 * BN) || (epi == EPI_STORE_BF16 && N >= 3 * BN);
   if (on != 2 && !dflt && !((force >> epi) & 1)) return SNX_E_SHAPE;   // on = 2 (snx_nt256_configure): take all
   if (!on || M < min_m || (N % 64) || (K % 64) || K < 64) return SNX_E_SHAPE;

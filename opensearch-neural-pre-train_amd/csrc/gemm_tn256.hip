@@ -43,6 +43,7 @@
 // -DSNX_GEMM_TRACE build.  Forms tried before this one (8-wave ping-pong with quadrant / half phases, 16x16x32 MFMAs):
 // 585 / 477 / 521 us in the same microbenchmark; 256x192 tiles with 192 accumulators: 482 us.
 #include "gemm_tn.h"
+#include "config.h"
 #include "snx.h"
 
 namespace {
@@ -390,12 +391,12 @@ int snx_launch_tn256(const TnGroup& g128, int M, hipStream_t st) {
   const int wt = NWG - s.nmain;
   // every workgroup should multiply about ntiles * nsteps / 256 half-steps; the tail workgroups flush once per tile
   // they touch, which SNX_TN256_TAIL_PCT (default 95) takes off their share
-  static const int tail_pct = getenv("SNX_TN256_TAIL_PCT") ? atoi(getenv("SNX_TN256_TAIL_PCT")) : 95;
+  const int tail_pct = SNX_DIAG_CFG(tn256_tail_pct, 95);
   s.tail_len = wt > 0 ? (int)((long)s.nsteps * wt * tail_pct / (100L * NWG)) : 0;
   s.main_len = s.nsteps - s.tail_len;
   s.tail_u = wt > 0 ? cdiv((long)s.ntiles * s.tail_len, wt) : 0;
   // diagnostics: 1 = no atomics, 2 = no DMA, 4 = L2-resident operands
-  static const int dbg = getenv("SNX_TN256_DBG") ? atoi(getenv("SNX_TN256_DBG")) : 0;
+  const int dbg = SNX_DIAG_CFG(tn256_dbg, 0);
   s.dbg = dbg;
   static bool attr[64] = {};                          // per device: the 160 KiB dynamic-LDS opt-in
   int devid = 0;

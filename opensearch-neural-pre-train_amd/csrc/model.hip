@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "config.h"
 #include "snx.h"
 
 bool snx_dec256_takes(int32_t T);   // splade_head.hip
@@ -199,15 +200,13 @@ struct Side {
   int enabled = -1;
   hipEvent_t done[2] = {nullptr, nullptr};   // grouped weight-gradient launch that last read buffer set k
   bool on() {
-    if (enabled < 0) {
-      const char* e = getenv("SNX_BWD_OVERLAP");
-      enabled = (e && e[0] == '0') ? 0 : 1;
+    if (enabled < 0) {                       // decided at the first backward (snx_configure "bwd_overlap" before it)
+      enabled = g_snx_cfg.bwd_overlap ? 1 : 0;
       if (enabled) {
         // LOWEST priority: the weight-gradient workgroups fill the slots the dX chain leaves free (last partial
-        // round of a GEMM, LayerNorm / attention phases) instead of competing with it.  SNX_SIDE_PRIO=0: default.
+        // round of a GEMM, LayerNorm / attention phases) instead of competing with it.  "side_prio" = 0: default.
         int least = 0, greatest = 0;
-        const char* pr = getenv("SNX_SIDE_PRIO");
-        const bool low = !(pr && pr[0] == '0');
+        const bool low = g_snx_cfg.side_prio != 0;
         if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
         if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, low ? least : 0) != hipSuccess) enabled = 0;
       }
@@ -277,7 +276,7 @@ extern "C" int snx_weight_cache_refresh(const snx_model_desc* d, const void* con
     return snx_cast_transpose_bf16((const float*)params[idx], base + ot, R, C, st);
   };
   RC(snx_cast_bf16((const float*)params[p.tok_emb()], base + c.emb, (int64_t)V * H, st));
-  const bool per_tensor = getenv("SNX_WCACHE_PER_TENSOR") != nullptr;   // A/B and tests: one launch per copy
+  const bool per_tensor = g_snx_cfg.wcache_per_tensor != 0;   // A/B and tests: one launch per copy
   if (!per_tensor && d->layers <= SNX_CAST_BATCH_MAX) {
     // one launch per shape class (Wqkv, attn.Wo, Wi, mlp.Wo), blockIdx.z = layer: 7 launches instead of 157
     CastBatch bq, bo, bi, bm;

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "gemm_core.h"
+#include "config.h"
 #include "snx.h"
 
 #ifndef SNX_DEC_GROUP
@@ -158,9 +159,7 @@ int snx_launch_decoder256(const void* Hd, const void* W, const float* bias, cons
 // SNX_DEC256=0 keeps the 128x128 kernel; the 256x192 form wants enough rows to fill its tiles.  (model.hip asks: the
 // 256x192 form takes all sequence groups of a pass in ONE call, the 128x128 kernel one call per group.)
 bool snx_dec256_takes(int32_t T) {
-  static const int dec256 = getenv("SNX_DEC256") ? atoi(getenv("SNX_DEC256")) : 1;
-  static const int dec256_min_t = getenv("SNX_DEC256_MIN_T") ? atoi(getenv("SNX_DEC256_MIN_T")) : 2048;
-  return dec256 && T >= dec256_min_t;
+  return g_snx_cfg.dec256 && T >= g_snx_cfg.dec256_min_t;
 }
 
 // row maxima [tiles, T] ushort (tiles = ceil(V / 128) for the 128x128 kernel, 2 ceil(V / 192) for the 256x192 form)
@@ -713,8 +712,7 @@ extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* 
                        row_off, V, max_seqlen);
   }
   SNX_CHECK_LAUNCH();
-  const char* penv = getenv("SNX_SPLADE_DH_PANELS");   // number of vocabulary panels; 0: the wave-per-row gather (A/B, tests)
-  const int panels = penv ? atoi(penv) : 16;
+  const int panels = g_snx_cfg.splade_dh_panels;       // number of vocabulary panels; 0: the wave-per-row gather (A/B, tests)
   if (det && panels > 0) {
     int32_t* items = (int32_t*)(sc + (((size_t)nseq * V * 8 + (size_t)nseq * (max_seqlen + 1) * 4 + 255) & ~(size_t)255));
     hipLaunchKernelGGL(splade_dh_items_kernel, dim3(1), dim3(256), 0, st, cu_seqlens, items, nseq, max_seqlen);

@@ -2,4 +2,4 @@
 SPLADE-ModernBERT training hot path.  PyTorch is used for device memory, streams and
 torch.distributed only; every hot-path op is a hand-written HIP kernel behind the C ABI declared
 in include/snx.h."""
-from ._lib import SnxError, SnxLibraryError, fn, lib, verify_exports  # noqa: F401
+from ._lib import SnxError, SnxLibraryError, config, configure, fn, lib, verify_exports  # noqa: F401

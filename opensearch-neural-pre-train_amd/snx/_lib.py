@@ -40,6 +40,8 @@ SIGNATURES = {
     "snx_attn_fwd_ex": (I32, [P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_attn_bwd_ex": (I32, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_attn_configure": (I32, [I32]),
+    "snx_configure": (I32, [C.c_char_p, I32]),
+    "snx_config_get": (I32, [C.c_char_p, P]),
     "snx_build_flags": (C.c_char_p, []),
     "snx_gemm_nt_rope": (I32, [P, P, P, P, P, I32, I32, I32, I32, P]),
     "snx_rope_rows": (I32, [P, P, P, I32, P]),
@@ -126,15 +128,41 @@ def _check_build_flags(L):
     warnings.warn(f"libsnx.so is a diagnostics build ({flags})")
 
 
+# environment variable -> key of snx_configure (include/snx.h).  The library itself reads no environment: this table is
+# the whole switchboard, applied once when the library is loaded.  Diagnostics builds (-DSNX_DIAG) accept more keys
+# through snx.configure(); they have no environment form.
+ENV_KEYS = {
+    "SNX_NT256": "nt256", "SNX_NT256_MIN_M": "nt256_min_m", "SNX_TN256": "tn256", "SNX_TN256_MIN_M": "tn256_min_m",
+    "SNX_DEC256": "dec256", "SNX_DEC256_MIN_T": "dec256_min_t", "SNX_BWD_OVERLAP": "bwd_overlap",
+    "SNX_ATTN_BWD_ONEPASS": "attn_bwd_onepass",
+}
+
+
 def _configure(L):
-    """Process-wide choices of the library, made HERE through its `snx_*_configure` entry points (include/snx.h) -- the
-    library itself reads no environment.  SNX_ATTN_BWD_ONEPASS=0: the two-pass attention backward (A/B, second opinion)."""
-    v = os.environ.get("SNX_ATTN_BWD_ONEPASS")
-    if v is not None:
-        L.snx_attn_configure.restype = C.c_int
-        L.snx_attn_configure.argtypes = [C.c_int32]
-        if L.snx_attn_configure(int(v)) != 0:
-            raise SnxLibraryError(f"SNX_ATTN_BWD_ONEPASS={v!r}: expected 0 or 1")
+    L.snx_configure.restype = C.c_int
+    L.snx_configure.argtypes = [C.c_char_p, C.c_int32]
+    for env, key in ENV_KEYS.items():
+        v = os.environ.get(env)
+        if v is not None and L.snx_configure(key.encode(), int(v)) != 0:
+            raise SnxLibraryError(f"{env}={v!r}: not a valid value for {key!r} (include/snx.h snx_configure)")
+
+
+def configure(**kw) -> None:
+    """snx.configure(key=value, ...): process-wide switches of the library (keys: include/snx.h snx_configure)."""
+    L = lib()
+    for k, v in kw.items():
+        if L.snx_configure(k.encode(), int(v)) != 0:
+            raise SnxError(f"snx_configure({k!r}, {v!r}) refused: unknown key or value out of range")
+
+
+def config(key: str) -> int:
+    out = C.c_int32(0)
+    L = lib()
+    L.snx_config_get.restype = C.c_int
+    L.snx_config_get.argtypes = [C.c_char_p, C.POINTER(C.c_int32)]
+    if L.snx_config_get(key.encode(), C.byref(out)) != 0:
+        raise SnxError(f"snx_config_get({key!r}): unknown key")
+    return out.value
 
 
 _bound = {}

@@ -120,3 +120,33 @@ def test_build_removes_the_object_of_a_failing_kernel(tmp_path, monkeypatch):
     with pytest.raises(A.AsmGuardError):
         B.build()
     assert not (obj / "decoder256.o").exists() and not (tmp_path / "libsnx_test.so").exists()
+
+
+@needs_hipcc
+def test_diagnostics_flavour_compiles_and_the_product_flavour_has_no_diagnostics_keys(tmp_path):
+    """Two flavours of the library: the product build compiles the concluded experiments' defaults in and refuses their
+    keys; -DSNX_DIAG (what the microbenchmark tools ask for) keeps them behind snx_configure.  The sources that carry
+    such switches must compile both ways, and no source may read the environment."""
+    import glob
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    for f in glob.glob(os.path.join(A.CSRC, "*.hip")) + glob.glob(os.path.join(A.CSRC, "*.h")):
+        assert "getenv" not in open(f).read(), f
+
+    def cc(name):
+        out = os.path.join(tmp_path, name + ".o")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", A.INCLUDE, "-I", A.CSRC,
+                            "-DSNX_DIAG", "-c", os.path.join(A.CSRC, name), "-o", out], capture_output=True, text=True)
+        return name, r.returncode, r.stderr[-2000:]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for name, rc, err in ex.map(cc, ["config.hip", "gemm.hip", "gemm_nt256.hip", "gemm_tn256.hip"]):
+            assert rc == 0, (name, err)
+    import snx
+    assert snx.config("nt256") == 1 and snx.config("attn_bwd_onepass") == 1
+    with pytest.raises(snx.SnxError):
+        snx.configure(nt256_dbg=1)                       # a diagnostics key: not in the product library
+    with pytest.raises(snx.SnxError):
+        snx.configure(no_such_key=1)
+    with pytest.raises(snx.SnxError):
+        snx.configure(nt256=7)                           # out of range

@@ -93,9 +93,13 @@ def test_gemm_f32_128_tiles_equal_the_64_tiles_bit_for_bit(dev, M, N, K, monkeyp
         torch.cuda.synchronize()
         return y, dx, dw
 
+    import snx
     got = run()
-    monkeypatch.setenv("SNX_F32_GEMM64", "1")
-    want = run()
+    snx.configure(f32_gemm64=1)
+    try:
+        want = run()
+    finally:
+        snx.configure(f32_gemm64=0)
     for a, b, name in zip(got, want, ("y", "dx", "dw")):
         assert torch.equal(a, b), name
     ref = r.double() + x.double() @ w.double().t()
@@ -301,9 +305,13 @@ def test_tiled_fp32_attention_on_ragged_and_holed_masks(dev, heads, hidden, S, m
     want, want_tw = O.splade_forward(params, cfg, ids, mask, "fp32")
     model = _build_model(cfg, params, dev).eval()
     with torch.no_grad():
+        import snx
         got, got_tw = model(ids.to(dev), mask.to(dev))
-        monkeypatch.setenv("SNX_F32_ATTN_ROWS", "1")
-        rows, rows_tw = model(ids.to(dev), mask.to(dev))
+        snx.configure(f32_attn_rows=1)
+        try:
+            rows, rows_tw = model(ids.to(dev), mask.to(dev))
+        finally:
+            snx.configure(f32_attn_rows=0)
     scale = float(want.abs().max())
     err = float((got.cpu() - want).abs().max())
     err_rows = float((rows.cpu() - want).abs().max())

@@ -368,8 +368,12 @@ def test_weight_cache_batched_refresh_equals_per_tensor(dev, full_setup, monkeyp
     a = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device=dev)
     b = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device=dev)
     check(fn("snx_weight_cache_refresh")(C.byref(rt._desc), ptrs, C.c_void_p(a.data_ptr()), st), "batched")
-    monkeypatch.setenv("SNX_WCACHE_PER_TENSOR", "1")
-    check(fn("snx_weight_cache_refresh")(C.byref(rt._desc), ptrs, C.c_void_p(b.data_ptr()), st), "per tensor")
+    import snx
+    snx.configure(wcache_per_tensor=1)
+    try:
+        check(fn("snx_weight_cache_refresh")(C.byref(rt._desc), ptrs, C.c_void_p(b.data_ptr()), st), "per tensor")
+    finally:
+        snx.configure(wcache_per_tensor=0)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
 

@@ -595,11 +595,14 @@ def test_splade_bwd(dev, B, S, V, H, monkeypatch):
     # the dHd gather has two forms (one wave per row / eight rows per wave walking the vocabulary in panels, the default
     # for vocabulary-ordered buckets): same accumulation order per row, so the same bits
     dHd_rows = torch.full((T, H), float("nan"), dtype=BF16, device=dev)
-    monkeypatch.setenv("SNX_SPLADE_DH_PANELS", "0")
+    import snx
+    snx.configure(splade_dh_panels=0)
     gE2, gb2 = gE0.clone(), gb0.clone()
-    check(fn("snx_splade_bwd")(_p(gs.to(dev)), _p(keys), _p(hdd), _p(Wd), _p(cud), _p(dHd_rows), _p(gE2), _p(gb2),
-                               _p(scratch), T, B, S, V, H, _stream()), "snx_splade_bwd")
-    monkeypatch.delenv("SNX_SPLADE_DH_PANELS")
+    try:
+        check(fn("snx_splade_bwd")(_p(gs.to(dev)), _p(keys), _p(hdd), _p(Wd), _p(cud), _p(dHd_rows), _p(gE2), _p(gb2),
+                                   _p(scratch), T, B, S, V, H, _stream()), "snx_splade_bwd")
+    finally:
+        snx.configure(splade_dh_panels=16)
     assert torch.equal(dHd.view(torch.int16), dHd_rows.view(torch.int16))
     # dense reference through autograd on the bf16 logits
     hl = hdd.float().requires_grad_(True)

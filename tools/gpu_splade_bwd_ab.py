@@ -8,6 +8,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "opensearch-neural-pre-train_amd"))
 import torch  # noqa: E402
+import snx
 from snx import ops  # noqa: E402
 from snx._lib import check, fn  # noqa: E402
 from snx.ops import _p, _stream  # noqa: E402
@@ -27,7 +28,7 @@ print("active entries:", int((sp > 0).sum()), "of", B * V, flush=True)
 scratch = torch.empty(fn("snx_splade_bwd_scratch_bytes")(B, S, V), dtype=torch.uint8, device=dev)
 out = {}
 for mode in os.environ.get("MODES", "0,32,16,64,0,32").split(","):
-    os.environ["SNX_SPLADE_DH_PANELS"] = mode
+    snx.configure(splade_dh_panels=int(mode))
     dHd = torch.full((T, H), float("nan"), dtype=torch.bfloat16, device=dev)
     gE = torch.zeros(V, H, device=dev)
     gb = torch.zeros(V, device=dev)
@@ -41,7 +42,7 @@ for mode in os.environ.get("MODES", "0,32,16,64,0,32").split(","):
     for _ in range(5):
         run()
     torch.cuda.synchronize()
-    print(f"SNX_SPLADE_DH_PANELS={mode}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms per call (dW + bucket + dHd)", flush=True)
+    print(f"splade_dh_panels={mode}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms per call (dW + bucket + dHd)", flush=True)
     out[mode] = dHd.clone()
 same = all(torch.equal(out["0"].view(torch.int16), v.view(torch.int16)) for v in out.values())
 print("dHd bit-identical:", same, flush=True)
