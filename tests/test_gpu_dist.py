@@ -180,6 +180,65 @@ def test_three_backward_micro_step_exchanges_once_after_the_last_backward(dev, n
         assert float(d.max()) <= 2 * 2 * 1e-3 * 1.01 and float(d.mean()) < 0.1 * 1e-3, (n, float(d.max()), float(d.mean()))
 
 
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_overlapped_exchange_beside_the_persistent_kernels_through_rccl(dev, nccl_world1, monkeypatch, mode):
+    """One accumulation window of a geometry whose backward runs on the PERSISTENT kernels (256x256 weight-gradient and
+    NT GEMMs, 256x192 decoder: thresholds lowered through snx_configure so that 2,176 token rows qualify), with the
+    gradient exchange overlapped with the last backward -- buckets through RCCL on the exchange stream while those
+    whole-CU kernels are in flight on 256 - SNX_EXCHANGE_RESERVED_CUS = 224 CUs -- against the un-overlapped path (no
+    buckets: one all-reduce of the whole buffer after the backward, every CU to the kernels).  At world size 1 every
+    collective is the identity, so the two accumulated gradients may differ by the float-atomic order of the weight
+    gradients only (<= 2e-6 of a tensor's largest element; a bucket reduced before its last producer, a slice exchanged
+    twice or the 224-workgroup schedules dropping work would be orders of magnitude above that), and nothing may fault
+    or hang with RCCL's channel workgroups resident beside the persistent ones.  What one GPU cannot show is the
+    contention itself (RCCL at world size 1 moves no data between devices): that needs a node."""
+    import snx
+    from oracle import splade_oracle as O
+    from snx._lib import fn
+    from src.model.losses import SPLADELossV33
+    from src.train.core import ddp_trainer as T
+    from tests.test_gpu_model import _build_model
+    cfg = O.EncoderConfig(vocab_size=3000, hidden_size=768, intermediate_size=1152, num_hidden_layers=4,
+                          num_attention_heads=12, local_attention=128, pad_token_id=2999)
+    params = O.perturb_params(O.init_params(cfg, seed=5), seed=6, scale=1.5, bias_mean=-0.1)
+    gen = torch.Generator().manual_seed(91)
+    batches = [O.synth_batch(8, 16, 128, cfg, gen, k=1, ragged=False) for _ in range(2)]     # 8 x (16 + 128 + 128) rows
+    monkeypatch.setenv("SNX_DIST_FORCE", "1")
+    monkeypatch.setenv("SNX_GRAD_EXCHANGE", mode)
+    monkeypatch.setenv("SNX_EXCHANGE_RESERVED_CUS", "32")
+    snx.configure(tn256_min_m=1024, nt256_min_m=1024, dec256_min_t=256)
+    try:
+        def run(n_buckets):
+            model = T.NativeDataParallel(_build_model(cfg, params, dev), n_buckets=n_buckets)
+            loss_fn = SPLADELossV33(temperature=20.0, flops_warmup_steps=4).to(dev)
+            seen = []
+            for i, b in enumerate(batches):
+                last = i + 1 == len(batches)
+                T.micro_step(model, loss_fn, b, 0, dev, len(batches), last_of_window=last)
+                seen.append(fn("snx_get_reserved_cus")())
+            model.sync_gradients()
+            torch.cuda.synchronize()
+            gs_ = model.module.runtime.grad_sync
+            return model.module.runtime.flat_grad.detach().clone(), gs_, seen, model
+        g_over, gs_, seen, m = run(3)
+        assert gs_ is not None and gs_.mode == mode and gs_.reserved_cus == 32
+        assert seen == [0, 0] and len(gs_.slices) == 3      # reserved only inside the armed backward, reset behind it
+        cov = sorted(gs_.slices)
+        assert cov[0][0] == 0 and cov[-1][1] == g_over.numel() and all(a[1] == b[0] for a, b in zip(cov, cov[1:])), cov
+        g_plain, gs0, _, _ = run(0)
+        assert gs0 is None
+    finally:
+        snx.configure(tn256_min_m=8192, nt256_min_m=8192, dec256_min_t=2048)
+    assert torch.isfinite(g_over).all() and float(g_over.abs().max()) > 0
+    off = 0
+    for name, p_ in enumerate(m.module.runtime.params):          # the flat buffer's own order
+        n = p_.numel()
+        a, b = g_over[off:off + n].double(), g_plain[off:off + n].double()
+        off += n
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * scale + 1e-12, (name, float((a - b).abs().max()), scale)
+
+
 def test_bucket_plan_covers_every_unit(dev):
     from snx.dist import BucketedGradSync
     for nb in (1, 2, 4, 8, 22, 40):
