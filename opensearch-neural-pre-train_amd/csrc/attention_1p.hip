@@ -145,14 +145,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
     doreg = *(const bf16x8*)(dobase + (long)gr * H + schunk * 8);
     oreg = *(const bf16x8*)(obase + (long)gr * H + schunk * 8);
   }
+  const int nk64 = (slen + 63) >> 6;                         // 64-row blocks of K that hold keys (a 64-token query: one)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = srow + 64 * i;
     const int gr = row < slen ? row : slen - 1;
-    kv[i] = *(const bf16x8*)(qbase + H + (long)gr * rs + schunk * 8);
+    if (i < nk64) kv[i] = *(const bf16x8*)(qbase + H + (long)gr * rs + schunk * 8);      // workgroup-uniform
   }
+  const bool has_keys = 32 * w < slen;                        // wave-uniform: this wave owns keys of the sequence
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) vb[ks] = *(const bf16x8*)(qbase + 2 * H + (long)keyr * rs + 16 * ks + 8 * h);
+  for (int ks = 0; ks < 4; ++ks)
+    if (has_keys) vb[ks] = *(const bf16x8*)(qbase + 2 * H + (long)keyr * rs + 16 * ks + 8 * h);
   const int64_t mk = mask[s0 + keyr];
   float lse_t = 0.f;
   int pos_t = 0;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    *(bf16x8*)(sK + (schunk >> 1) * PS_K + i * 64 * 32 + p_off(srow, schunk & 1)) = kv[i];
+    if (i < nk64) *(bf16x8*)(sK + (schunk >> 1) * PS_K + i * 64 * 32 + p_off(srow, schunk & 1)) = kv[i];
   if (tid < MAXK) {
     sLse[tid] = -lse_t / scale;                               // S' = q k - lse / scale, p = exp(scale S')
     sPos[tid] = pos_t;
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
   // Through LDS (the slice images are free now; 8 KiB per wave), so that the global stores are whole 128-byte rows in 16-byte
   // pieces: sixteen 8-byte stores per lane at a row stride are bound by store ISSUE (32-64 lines per instruction).
   WG_BARRIER();
-  {
+  if (has_keys) {
     char* stg = smem + w * 8192;                               // [dK | dV][32 keys][64 d] bf16, 16-B chunk ^ (key & 7)
     f32x2 t[16];
     if (rope_tab) {

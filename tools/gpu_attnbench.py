@@ -4,10 +4,12 @@ import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "opensearch-neural-pre-train_amd"))
 import torch
+import snx
 from snx import ops
 from snx._lib import fn, check
 
 dev = torch.device("cuda:0")
+DEFAULT = snx.config("attn_bwd_onepass")
 BF16 = torch.bfloat16
 
 
@@ -36,15 +38,15 @@ for name, lens in [("fused q+p+n", [64] * 64 + [256] * 128), ("docs only", [256]
         for gr in ([None, grp] if grp else [None]):
             out, lse = ops.attn_fwd(qkv, cu, mask, 256, heads, w, validate=False, groups=gr)
             f = timeit(lambda: ops.attn_fwd(qkv, cu, mask, 256, heads, w, validate=False, groups=gr))
-            b = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False, groups=gr))
-            d1 = ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False, groups=gr).float()
-            check(fn("snx_attn_configure")(0), "snx_attn_configure")
-            b2 = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False, groups=gr))
-            d2 = ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False, groups=gr).float()
-            check(fn("snx_attn_configure")(1), "snx_attn_configure")
-            rel = float((d1 - d2).norm() / d2.norm())
-            print(f"{name} window={w} groups={'yes' if gr else 'no'}: fwd {f:.1f} us, bwd one-pass {b:.1f} us, "
-                  f"two-pass {b2:.1f} us, rel diff {rel:.2e}", flush=True)
+            res = {}
+            for mode in (1, 0):
+                snx.configure(attn_bwd_onepass=mode)
+                t = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False, groups=gr))
+                res[mode] = (t, ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False, groups=gr).float())
+            snx.configure(attn_bwd_onepass=DEFAULT)
+            rel1 = float((res[1][1] - res[0][1]).norm() / res[0][1].norm())
+            print(f"{name} window={w} groups={'yes' if gr else 'no'}: fwd {f:.1f} us, bwd one-pass {res[1][0]:.1f} us, "
+                  f"two-kernel {res[0][0]:.1f} us, rel diff {rel1:.2e}", flush=True)
 
 # the model's call: inverse RoPE fused into the dq / dk stores
 lens = [64] * 64 + [256] * 128
@@ -59,11 +61,11 @@ grp = [(0, 64, 64), (64, 128, 256)]
 for w in (-1, 64):
     out, lse = ops.attn_fwd(qkv, cu, mask, 256, heads, w, validate=False, groups=grp)
     for mode in (1, 0):
-        check(fn("snx_attn_configure")(mode), "snx_attn_configure")
+        snx.configure(attn_bwd_onepass=mode)
         b = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False, groups=grp,
                                         rope_table=tab, pos=pos))
-        print(f"fused + inverse RoPE window={w} {'one-pass' if mode else 'two-pass'}: bwd {b:.1f} us", flush=True)
-    check(fn("snx_attn_configure")(1), "snx_attn_configure")
+        print(f"fused + inverse RoPE window={w} {('two-kernel', 'one-pass')[mode]}: bwd {b:.1f} us", flush=True)
+    snx.configure(attn_bwd_onepass=DEFAULT)
 
 # queries alone: live blocks only (max_seqlen 64) vs 3 of 4 blocks exiting at once (max_seqlen 256)
 cu = (torch.arange(65, dtype=torch.int32) * 64).to(dev)
