@@ -225,7 +225,8 @@ int snx_gemm_tn_accum_group(const snx_tn_problem* probs /*[host]*/, int32_t npro
  * maps its SNX_* variables onto these keys once, at load time (snx/_lib.py), tests and tools call them directly.
  * Keys (default): nt256 (1; 0 off, 2 every eligible shape), nt256_min_m (8192), tn256 (1), tn256_min_m (8192),
  * dec256 (1), dec256_min_t (2048), bwd_overlap (1), side_prio (1), attn_streaming (0), attn_bwd_onepass (1),
- * splade_dh_panels (16), f32_gemm64 (0), f32_attn_rows (0), wcache_per_tensor (0); diagnostics builds (-DSNX_DIAG) add
+ * splade_dh_panels (16), f32_gemm64 (0), f32_attn_rows (0), wcache_per_tensor (0), resid_in_ln (0: residual add in the
+ * Wo GEMMs' epilogue; 1: plain bf16 GEMM + add inside the following LayerNorm, same bits); diagnostics builds (-DSNX_DIAG) add
  * gemm_cg, gemm_dbg, gemm_mid, tn_splits, nt256_cg, nt256_dbg, nt256_force, tn256_tail_pct, tn256_dbg.  Unknown key or
  * value out of range: SNX_E_ARG. */
 int snx_configure(const char* key, int32_t value);
@@ -238,6 +239,10 @@ int snx_get_reserved_cus(void);
 
 /* LayerNorm without bias (hf:61,312,314,420,487), fp32 in -> bf16 out. */
 int snx_ln_fwd(const float* h, const float* w, void* x_out, int32_t T, int32_t H, float eps, hipStream_t stream);
+/* h_out = h + float(y) (y [T,H] bf16: a Linear's output joining the fp32 residual stream, hf:331-332), x_out = bf16(LN(h_out)):
+ * the residual add done inside the LayerNorm that follows it (process switch "resid_in_ln"). */
+int snx_ln_fwd_add(const float* h, const void* y, const float* w, float* h_out, void* x_out, int32_t T, int32_t H,
+                   float eps, hipStream_t stream);
 /* ModernBertEmbeddings.forward (hf:64-71): h = LN(E[ids]) fp32, x0 = bf16(h). */
 int snx_embed_ln_fwd(const int64_t* ids, const float* E, const float* w, float* h_out, void* x0_out, int32_t T,
                      int32_t H, float eps, hipStream_t stream);

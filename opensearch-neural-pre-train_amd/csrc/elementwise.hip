@@ -188,6 +188,8 @@ __device__ __forceinline__ float ln_normalize(RowVec<NV>& x, int H, float eps) {
 
 // MODE 0: src = h fp32 rows.  MODE 1: src = E[ids[t]] (embedding gather), also writes h fp32.
 // MODE 2: src = gelu(bf16 d) evaluated on the bf16 tensor (head: LN(gelu(dense))).
+// MODE 3: src = h fp32 + bf16 d (the residual add of hf:331-332 done HERE: a Linear's bf16 output joins the fp32 stream),
+//         also writes the sum to h_out -- what the residual epilogue of the Wo GEMMs computes, bit for bit.
 template <int NV, int MODE>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h, const int64_t* __restrict__ ids,
                                                      const float* __restrict__ E, const bf16_t* __restrict__ d,
@@ -202,6 +204,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h
     x.load_f32(h + (long)t * H, lane);
   } else if (MODE == 1) {
     x.load_f32(E + ids[t] * (long)H, lane);
+  } else if (MODE == 3) {
+    RowVec<NV> y;
+    x.load_f32(h + (long)t * H, lane);
+    y.load_bf16(d + (long)t * H, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) x.v[i] += y.v[i];
+    x.store_f32(h_out + (long)t * H, lane);
   } else {
     x.load_bf16(d + (long)t * H, lane);
 #pragma unroll
@@ -238,6 +247,16 @@ extern "C" int snx_ln_fwd(const float* h, const float* w, void* x_out, int32_t T
   if (bad_h(H)) return SNX_E_SHAPE;
   DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<NV, 0>), dim3(cdiv(T, ROWS_PER_BLOCK)), dim3(256), 0, st, h,
                                     nullptr, nullptr, nullptr, w, nullptr, (bf16_t*)x_out, nullptr, T, H, eps));
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+
+extern "C" int snx_ln_fwd_add(const float* h, const void* y, const float* w, float* h_out, void* x_out, int32_t T,
+                              int32_t H, float eps, hipStream_t st) {
+  if (!h || !y || !w || !h_out || !x_out || T <= 0) return SNX_E_ARG;
+  if (bad_h(H)) return SNX_E_SHAPE;
+  DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<NV, 3>), dim3(cdiv(T, ROWS_PER_BLOCK)), dim3(256), 0, st, h,
+                                    nullptr, nullptr, (const bf16_t*)y, w, h_out, (bf16_t*)x_out, nullptr, T, H, eps));
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }

@@ -348,22 +348,40 @@ extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* par
   { PROF(PC_ROPE, 2.0 * T * 512);
     RC(snx_rope_rows(rope_global, pos, (float*)(sv + s.rope_rows[0]), T, st));
     RC(snx_rope_rows(rope_local, pos, (float*)(sv + s.rope_rows[1]), T, st)); }
+  // "resid_in_ln": the Wo GEMMs store their bf16 result (ybuf: the head's dense buffer, free until the layers are done)
+  // and the residual add h + float(y) happens inside the LayerNorm that follows every one of them -- the same bits as the
+  // GEMM's residual epilogue, the fp32 stream's read + write moved from an MFMA-bound kernel to an HBM-bound one.
+  const bool ril = g_snx_cfg.resid_in_ln != 0;
+  char* ybuf = sv + s.dd;
   for (int l = 0; l < L; ++l) {
     const bool global = (l % d->global_every) == 0;
-    if (l > 0) { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l), F(p.attn_norm(l)), sv + s.x_attn[l], T, H, d->ln_eps, st)); }
+    if (l > 0 && !ril) { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l), F(p.attn_norm(l)), sv + s.x_attn[l], T, H, d->ln_eps, st)); }
     { PROF(PC_GEMM_NT, 2.0 * T * 3 * H * H);      // Wqkv + RoPE fused
       RC(snx_gemm_nt_rope_rows(sv + s.x_attn[l], wc + c.wqkv[l], sv + s.qkv[l], global ? rope_global : rope_local, pos,
                                (const float*)(sv + s.rope_rows[global ? 0 : 1]), 2 * H, T, 3 * H, H, st)); }
     { PROF(PC_ATTN_FWD, 4.0 * H * attn_pairs(groups, nseq, max_seqlen, global ? -1 : d->window));
       RC(snx_attn_fwd_ex(sv + s.qkv[l], cu_seqlens, mask, sv + s.attn[l], (float*)(sv + s.lse[l]), groups, T, nseq,
                          max_seqlen, d->heads, d->head_dim, global ? -1 : d->window, st)); }
-    { PROF(PC_GEMM_NT_RESID, 2.0 * TH * H); RC(snx_gemm_nt_resid(sv + s.attn[l], wc + c.wo[l], hbuf(2 * l), hbuf(2 * l + 1), T, H, H, st)); }
-    { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l + 1), F(p.mlp_norm(l)), sv + s.x_mlp[l], T, H, d->ln_eps, st)); }
+    if (ril) {
+      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * H); RC(snx_gemm_nt_bf16(sv + s.attn[l], wc + c.wo[l], ybuf, T, H, H, st)); }
+      { PROF(PC_LN_FWD, TH * 12); RC(snx_ln_fwd_add(hbuf(2 * l), ybuf, F(p.mlp_norm(l)), hbuf(2 * l + 1), sv + s.x_mlp[l], T, H, d->ln_eps, st)); }
+    } else {
+      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * H); RC(snx_gemm_nt_resid(sv + s.attn[l], wc + c.wo[l], hbuf(2 * l), hbuf(2 * l + 1), T, H, H, st)); }
+      { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l + 1), F(p.mlp_norm(l)), sv + s.x_mlp[l], T, H, d->ln_eps, st)); }
+    }
     { PROF(PC_GEMM_NT, 2.0 * T * 2 * I * H);      // Wi + GeGLU fused (u kept in the interleaved column order)
       RC(snx_gemm_nt_geglu_fwd(sv + s.x_mlp[l], wc + c.wi[l], sv + s.u[l], sv + s.y[l], T, 2 * I, H, st)); }
-    { PROF(PC_GEMM_NT_RESID, 2.0 * TH * I); RC(snx_gemm_nt_resid(sv + s.y[l], wc + c.wom[l], hbuf(2 * l + 1), hbuf(2 * l + 2), T, H, I, st)); }
+    if (ril) {
+      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * I); RC(snx_gemm_nt_bf16(sv + s.y[l], wc + c.wom[l], ybuf, T, H, I, st)); }
+      const bool last = l + 1 == L;
+      { PROF(PC_LN_FWD, TH * 12);
+        RC(snx_ln_fwd_add(hbuf(2 * l + 1), ybuf, F(last ? p.final_norm() : p.attn_norm(l + 1)), hbuf(2 * l + 2),
+                          last ? sv + s.xf : sv + s.x_attn[l + 1], T, H, d->ln_eps, st)); }
+    } else {
+      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * I); RC(snx_gemm_nt_resid(sv + s.y[l], wc + c.wom[l], hbuf(2 * l + 1), hbuf(2 * l + 2), T, H, I, st)); }
+    }
   }
-  { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * L), F(p.final_norm()), sv + s.xf, T, H, d->ln_eps, st)); }
+  if (!ril) { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * L), F(p.final_norm()), sv + s.xf, T, H, d->ln_eps, st)); }
   { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(sv + s.xf, wc + c.dense, sv + s.dd, T, H, H, st)); }
   { PROF(PC_LN_FWD, TH * 4); RC(snx_gelu_ln_fwd(sv + s.dd, F(p.head_norm()), sv + s.hd, T, H, d->ln_eps, st)); }
   {

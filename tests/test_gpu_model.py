@@ -38,6 +38,9 @@ def _report(name, obj):
         f.write(json.dumps({"test": name, **obj}) + "\n")
 
 
+RESID_IN_LN_DEFAULT = 0          # (tests restore the process-wide switch they flip)
+
+
 def _small_cfg():
     from oracle import splade_oracle as O
     return O.EncoderConfig(vocab_size=1000, hidden_size=256, intermediate_size=384, num_hidden_layers=4,
@@ -411,6 +414,34 @@ def test_forward_many_equals_separate_passes(dev):
     for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         cos, rel = _grad_stats(p2.grad, p1.grad)
         assert cos > 0.99999 and rel < 2e-3, (n1, cos, rel)      # fp32 atomics order only
+
+
+def test_residual_add_in_the_layernorm_equals_the_gemm_epilogue(dev):
+    """snx_configure "resid_in_ln": the Wo GEMMs store bf16 and the following LayerNorm adds it to the fp32 stream
+    (snx_ln_fwd_add) instead of the GEMM's residual epilogue -- h + float(bf16(A W^T)) either way: identical outputs, and
+    gradients that differ by the float-atomic order of the weight gradients only (the backward reads the same saved h)."""
+    import snx
+    from oracle import splade_oracle as O
+    cfg = _small_cfg()
+    params = O.perturb_params(O.init_params(cfg, seed=3), seed=4, scale=2.0, bias_mean=-0.1)
+    gen = torch.Generator().manual_seed(56)
+    ids, mask = O.synth_ids(6, 130, cfg, gen, ragged=True)
+    outs = []
+    try:
+        for mode in (0, 1):
+            snx.configure(resid_in_ln=mode)
+            m = _build_model(cfg, params, dev)
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                s_, t_ = m(ids.to(dev), mask.to(dev))
+            (s_ * torch.linspace(0.5, 1.5, s_.shape[-1], device=dev)).sum().backward()
+            outs.append((s_.detach(), t_.detach(), {n: p.grad.clone() for n, p in m.named_parameters()}))
+    finally:
+        snx.configure(resid_in_ln=RESID_IN_LN_DEFAULT)
+    (s0, t0, g0), (s1, t1, g1) = outs
+    assert torch.equal(s0, s1) and torch.equal(t0, t1)
+    for n in g0:
+        cos, rel = _grad_stats(g1[n], g0[n])
+        assert cos > 0.99999 and rel < 2e-3, (n, cos, rel)
 
 
 def test_fused_adamw_matches_torch_adamw(dev):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the summaries of the last `bash tools/gpu_profile_round.sh rNN` (merged back under gpurun_out/) into profiles/
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/prof_$R
 cp $O/bench_n1.json profiles/${R}_bench_n1.json
 cp $O/bench_cfg5_n1.json profiles/${R}_bench_cfg5_n1.json

@@ -34,6 +34,8 @@ for w in (-1, 64):
     torch.cuda.synchronize()
     fset(0)
     b = buf.view(nb, 16).cpu().double()
+    b = b[b[:, 12] > 0]                                   # workgroups that ran (a persistent launch has fewer)
+    nb = b.shape[0]
     med = lambda x: float(x.median())   # noqa: E731
     names = ["prologue", "s0 top+barrier", "s0 phase 1", "s0 barrier", "s0 phase 2", "s1 top+barrier", "s1 phase 1",
              "s1 barrier", "s1 phase 2"]
