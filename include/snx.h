@@ -225,8 +225,8 @@ int snx_gemm_tn_accum_group(const snx_tn_problem* probs /*[host]*/, int32_t npro
  * maps its SNX_* variables onto these keys once, at load time (snx/_lib.py), tests and tools call them directly.
  * Keys (default): nt256 (1; 0 off, 2 every eligible shape), nt256_min_m (8192), tn256 (1), tn256_min_m (8192),
  * dec256 (1), dec256_min_t (2048), bwd_overlap (1), side_prio (1), attn_streaming (0), attn_bwd_onepass (1),
- * splade_dh_panels (16), f32_gemm64 (0), f32_attn_rows (0), wcache_per_tensor (0), resid_in_ln (0: residual add in the
- * Wo GEMMs' epilogue; 1: plain bf16 GEMM + add inside the following LayerNorm, same bits); diagnostics builds (-DSNX_DIAG) add
+ * splade_dh_panels (16), f32_gemm64 (0), f32_attn_rows (0), wcache_per_tensor (0), resid_in_ln (1: the Wo GEMMs store
+ * bf16 and the residual add happens inside the following LayerNorm; 0: in the GEMMs' fp32 epilogue, same bits); diagnostics builds (-DSNX_DIAG) add
  * gemm_cg, gemm_dbg, gemm_mid, tn_splits, nt256_cg, nt256_dbg, nt256_force, tn256_tail_pct, tn256_dbg.  Unknown key or
  * value out of range: SNX_E_ARG. */
 int snx_configure(const char* key, int32_t value);

@@ -38,7 +38,7 @@ def _report(name, obj):
         f.write(json.dumps({"test": name, **obj}) + "\n")
 
 
-RESID_IN_LN_DEFAULT = 0          # (tests restore the process-wide switch they flip)
+RESID_IN_LN_DEFAULT = 1          # (tests restore the process-wide switch they flip)
 
 
 def _small_cfg():
