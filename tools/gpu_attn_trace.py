@@ -13,7 +13,8 @@ from snx._lib import lib  # noqa: E402
 
 dev = torch.device("cuda:0")
 heads = 12
-lens = [256] * 128
+lens = ([64] * 64 + [256] * 128) if "fused" in sys.argv else [256] * 128
+groups = [(0, 64, 64), (64, 128, 256)] if "fused" in sys.argv else None
 cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
 T = int(cu[-1])
 mask = torch.ones(T, dtype=torch.int64, device=dev)
@@ -24,16 +25,22 @@ fset = L.snx_attn1p_trace_set
 fset.restype = C.c_int
 fset.argtypes = [C.c_void_p]
 for w in (-1, 64):
-    out, lse = ops.attn_fwd(qkv, cu, mask, 256, heads, w, validate=False)
+    out, lse = ops.attn_fwd(qkv, cu, mask, 256, heads, w, validate=False, groups=groups)
     for _ in range(3):
-        ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False)
-    nb = 128 * heads
+        ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False, groups=groups)
+    nb = len(lens) * heads
     buf = torch.zeros(nb * 16, dtype=torch.int64, device=dev)
     fset(buf.data_ptr())
-    ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False)
+    ops.attn_bwd(qkv, out, dout, lse, cu, mask, 256, heads, w, validate=False, groups=groups)
     torch.cuda.synchronize()
     fset(0)
     b = buf.view(nb, 16).cpu().double()
+    if groups:                                             # documents first (longest group first), then the queries
+        nd = 128 * heads
+        for name, part in (("documents", b[:nd]), ("queries", b[nd:])):
+            print(f"  {name}: {part.shape[0]} workgroups, wall median {float(((part[:, 13] - part[:, 12]) * 10).median()):.0f} ns, "
+                  f"first start {float(part[:, 12].min() - b[:, 12].min()) * 10 / 1e3:.1f} us, last end "
+                  f"{float(part[:, 13].max() - b[:, 12].min()) * 10 / 1e3:.1f} us after the kernel's first workgroup", flush=True)
     b = b[b[:, 12] > 0]                                   # workgroups that ran (a persistent launch has fewer)
     nb = b.shape[0]
     med = lambda x: float(x.median())   # noqa: E731
