@@ -129,10 +129,32 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_fwd_unit_kernel(const bf1
   const int H = heads * 64;
   const long rs = 3L * H;
   const bf16_t* qbase = qkv + (long)s0 * rs + head * 64;
+  // Q fragments of a 16-row group (B operand: lane = query li, 8 consecutive d); rows past the sequence read its last row
+  auto load_q = [&](int rg, bf16x8 (&q)[2]) __attribute__((always_inline)) {
+    const int qp = rg * 16 + li;
+    const int qrow = qp < slen ? qp : (slen > 0 ? slen - 1 : 0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) q[c] = *(const bf16x8*)(qbase + (long)qrow * rs + c * 32 + g * 8);
+  };
+  // ONE round trip to memory before the barrier: the key mask and the first row group's Q fragments are requested ahead of
+  // the K / V rows (as three trips -- images, then the mask, then Q after the barrier -- each cost every workgroup a
+  // memory latency that nothing else on the CU covered)
+  bf16x8 qf[2];
   if (t.live) {
+    const int key = t.lt < slen ? t.lt : (slen > 0 ? slen - 1 : 0);
+    // (asm: as a plain load hipcc sinks it below the image writes, next to its use, and waits there)
+    int64_t mv;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(mv) : "v"(mask + s0 + key) : "memory");
+    load_q(t.lw, qf);
     load_image<2>(qbase + H, rs, t, sK);
     load_image<2>(qbase + 2 * H, rs, t, sV);
-    load_valid(mask, t, sValid, sAll);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mv));           // the oldest request: long there after the image writes
+    if (t.lt < ntu * 64) {                     // whole waves: ntu * 64 and the unit's first thread are multiples of 64
+      const bool v = t.lt < slen && mv != 0;
+      sValid[t.lt] = v ? 1 : 0;
+      const unsigned long long all = __ballot(v);
+      if ((t.lt & 63) == 0) sAll[t.lt >> 6] = (all == ~0ull) ? 1 : 0;
+    }
   }
   __syncthreads();
   if (!t.live) return;
@@ -141,10 +163,8 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_fwd_unit_kernel(const bf1
   const int row_lo = rg * 16;
   if (row_lo >= slen) break;
   const int qpos = row_lo + li;
-  const int qrow = qpos < slen ? qpos : slen - 1;
-  bf16x8 qf[2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) qf[c] = *(const bf16x8*)(qbase + (long)qrow * rs + c * 32 + g * 8);
+  bf16x8 qn[2];
+  load_q(rg + t.wpu, qn);                                   // the next group's, under this group's tiles
 
   int j_lo, j_hi;
   tile_range(window, row_lo, slen, j_lo, j_hi);
@@ -237,6 +257,7 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_fwd_unit_kernel(const bf1
       *(bf16x4*)(orow + d * 16) = (bf16x4){f2bf(o[d][0] * inv), f2bf(o[d][1] * inv), f2bf(o[d][2] * inv), f2bf(o[d][3] * inv)};
     if (g == 0) lse[(long)head * T + s0 + qpos] = (m_run + __log2f(l_run)) * LN2;   // natural-log LSE
   }
+  qf[0] = qn[0]; qf[1] = qn[1];
   }
 }
 
