@@ -131,7 +131,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
   float* sDel = (float*)(smem + OFF_DEL);
   int* sPos = (int*)(smem + OFF_POS);
   const int nrow = ((slen + 31) >> 5) << 5;                  // rows of K / of the row constants that are ever read
-  const int srow = tid >> 3, schunk = tid & 7;               // this thread's 16-B piece of a 64-row slice
+  // this thread's 16-B piece of a 64-row slice (a wave: 8 rows x 128 B).  8 CONTIGUOUS lanes write 4 rows x 32 B of one plane =
+  // 128 contiguous bytes: ds_write_b128 works in groups of 8 lanes over 32 banks, and chunk = lane & 7 would put the four planes of
+  // a row (17 / 65 x 128 B apart) on the same banks -- a 4-way conflict on every image write
+  const int srow = 8 * (tid >> 6) + 4 * ((tid >> 5) & 1) + ((tid >> 1) & 3), schunk = 2 * ((tid >> 3) & 3) + (tid & 1);
   const int sdst = (schunk >> 1) * PS_S + p_off(srow, schunk & 1);
 
   // ---- unit prologue.  Every global load is issued before anything waits (one round trip: with one workgroup per CU
@@ -220,9 +223,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
       float dl = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) dl = fmaf(bf2f(doreg[e]), bf2f(oreg[e]), dl);
-      dl += __shfl_xor(dl, 1, 64);
-      dl += __shfl_xor(dl, 2, 64);
-      dl += __shfl_xor(dl, 4, 64);
+      dl += __shfl_xor(dl, 1, 64);                           // the row's eight pieces: lane bits 0, 3, 4
+      dl += __shfl_xor(dl, 8, 64);
+      dl += __shfl_xor(dl, 16, 64);
       if (schunk == 0) sDel[q0 + srow] = -dl;
     }
     if (sl + 1 < nsl) {                                        // next slice: in flight during this one
