@@ -155,7 +155,7 @@ def test_tiny_loss_and_all_gradients_match_the_reference_fp32(dev):
     loss, d = lf(anchor_repr=q, positive_repr=p, negative_repr=n.view(q.shape[0], meta["num_negatives"], -1),
                  global_step=meta["global_step"], teacher_pos_scores=D(b["teacher_pos_scores"]),
                  teacher_neg_scores=D(b["teacher_neg_scores"]))
-    assert abs(float(loss) - float(z["out::loss"])) <= 2e-5 * max(1.0, abs(float(z["out::loss"])))
+    assert abs(float(loss.detach()) - float(z["out::loss"])) <= 2e-5 * max(1.0, abs(float(z["out::loss"])))
     for k, v in meta["loss_dict"].items():
         assert float(d[k]) == pytest.approx(v, rel=5e-5, abs=1e-5), k
     loss.backward()
