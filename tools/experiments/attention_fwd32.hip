@@ -3,7 +3,7 @@
 // library's forward), but not faster than the 16x16 kernel of csrc/attention_unit.hip on the training shapes
 // (fused 64 x q64 + 128 x d256, 12 heads: 62.7 / 51.0 us global / window-64 against 55-57 / 47-48 us), so it was not adopted.
 // Build and time it with tools/gpu_fwd32_probe.py; the measurements and what they showed are in DESIGN.md section 4
-// ("attention forward on the 32x32 MFMA") and profiles/r04_attn_fwd32_probe.txt.
+// ("attention forward on the 32x32 MFMA") and profiles/r04_experiments.txt.
 //
 //   workgroup  = 8 waves = one per CU, walking items (a 256-token document, or four 64-token queries) grid apart; the item's
 //                Q, K and V rows resident in LDS in PLANE form (one image serves row fragments and transposed fragments
