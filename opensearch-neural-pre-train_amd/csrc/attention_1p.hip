@@ -471,11 +471,8 @@ int attn_bwd_onepass(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, c
     if (b > 0x7fffffffL) return SNX_E_SHAPE;
     sc.bend[i] = (int)b;
   }
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_1p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_1P);
-    once = true;
-  }
+  static LdsOptIn optin;
+  if (const int rc = optin.ensure((const void*)attn_bwd_1p_kernel, LDS_1P)) return rc;
   hipLaunchKernelGGL(attn_bwd_1p_kernel, dim3((unsigned)b), dim3(512), LDS_1P, st, qkv, out, dout, lse, cu_seqlens, mask,
                      dqkv, rope_tab, pos, T, heads, window, 0.125f, sc);
   SNX_CHECK_LAUNCH();

@@ -524,10 +524,6 @@ int build_unit_sched(UnitSched& sc, int& blocks, const int32_t* groups, int head
   return SNX_OK;
 }
 
-void allow_lds(const void* kern) {
-  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)UNIT_LDS);
-}
-
 }  // namespace
 
 int attn_unit_fwd(const bf16_t* qkv, const int32_t* cu_seqlens, const int64_t* mask, bf16_t* out, float* lse, int T,
@@ -536,8 +532,8 @@ int attn_unit_fwd(const bf16_t* qkv, const int32_t* cu_seqlens, const int64_t* m
   int blocks;
   const int rc = build_unit_sched(sc, blocks, groups, heads);
   if (rc != SNX_OK) return rc;
-  static bool once = false;
-  if (!once) { allow_lds((const void*)attn_fwd_unit_kernel); once = true; }
+  static LdsOptIn optin;
+  if (const int rc2 = optin.ensure((const void*)attn_fwd_unit_kernel, (int)UNIT_LDS)) return rc2;
   hipLaunchKernelGGL(attn_fwd_unit_kernel, dim3(blocks), dim3(NTMAX * 128), UNIT_LDS, st, qkv, cu_seqlens, mask, out,
                      lse, T, heads, window, 0.125f, sc);
   SNX_CHECK_LAUNCH();
@@ -560,12 +556,9 @@ int attn_unit_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, cons
   int blocks;
   const int rc = build_unit_sched(sc, blocks, groups, heads);
   if (rc != SNX_OK) return rc;
-  static bool once = false;
-  if (!once) {
-    allow_lds((const void*)attn_bwd_dq_unit_kernel);
-    allow_lds((const void*)attn_bwd_dkv_unit_kernel);
-    once = true;
-  }
+  static LdsOptIn optin_dq, optin_dkv;
+  if (const int rc2 = optin_dq.ensure((const void*)attn_bwd_dq_unit_kernel, (int)UNIT_LDS)) return rc2;
+  if (const int rc2 = optin_dkv.ensure((const void*)attn_bwd_dkv_unit_kernel, (int)UNIT_LDS)) return rc2;
   hipLaunchKernelGGL(attn_bwd_dq_unit_kernel, dim3(blocks), dim3(NTMAX * 128), UNIT_LDS, st, qkv, out, dout, lse,
                      delta, cu_seqlens, mask, dqkv, rope_tab, pos, T, heads, window, 0.125f, sc);
   SNX_CHECK_LAUNCH();

@@ -91,6 +91,22 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Opt-in to more than 64 KiB of dynamic LDS for one kernel, once PER DEVICE (hipFuncSetAttribute is per device; a process
+// that moves to a second device would otherwise launch without it there).  One static instance per kernel; returns SNX_OK,
+// SNX_E_ARG (no current device) or the HIP error code.
+struct LdsOptIn {
+  bool done[64] = {};
+  int ensure(const void* kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SNX_E_ARG;
+    if (done[dev]) return SNX_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done[dev] = true;
+    return SNX_OK;
+  }
+};
+
 // one launch for the bf16 copy + transposed bf16 copy of up to 64 same-shaped fp32 matrices (elementwise.hip; used by the
 // weight-cache refresh in model.hip)
 #define SNX_CAST_BATCH_MAX 64

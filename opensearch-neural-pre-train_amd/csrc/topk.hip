@@ -159,12 +159,8 @@ extern "C" int snx_sparse_topk(const float* rep, const uint8_t* allowed, float* 
   while (P < (k > 0 ? k : 1)) P <<= 1;
   const size_t lds = (size_t)P * 8;
   if (lds > 48 * 1024) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)sparse_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                TK_KMAX * 8);
-      attr = true;
-    }
+    static LdsOptIn optin;
+    if (const int rc = optin.ensure((const void*)sparse_topk_kernel, TK_KMAX * 8)) return rc;
   }
   hipLaunchKernelGGL(sparse_topk_kernel, dim3(B), dim3(TK_THREADS), lds, st, rep, allowed, V, k, cap, out_val,
                      out_idx, out_cnt, out_sorted);

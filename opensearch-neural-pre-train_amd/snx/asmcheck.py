@@ -57,7 +57,8 @@ def kernels_of(asm: str) -> Dict[str, List[str]]:
     out: Dict[str, List[str]] = {}
     cur = None
     for line in asm.splitlines():
-        m = re.match(r"^([A-Za-z_][\w.$]*):\s*(;.*)?$", line)
+        # global symbols AND hipcc's local labels (".LBB0_12:", often followed by "; =>This Inner Loop Header ...")
+        m = re.match(r"^(\.?[A-Za-z_][\w.$]*):\s*(;.*)?$", line)
         if m and not m.group(1).startswith(".L"):
             cur = m.group(1)
             out[cur] = []

@@ -134,12 +134,12 @@ class BucketedGradSync:
         self.log: List[tuple] = []                       # ("fwd"|"bwd"|"exchange"|"reduce", ...) call order (tests)
         self.keep_log = os.environ.get("SNX_GRAD_SYNC_LOG", "0") == "1"
         # CUs the persistent GEMM kernels (one workgroup per CU) leave to RCCL's channel workgroups while the exchange
-        # overlaps the backward (include/snx.h snx_set_reserved_cus); 0 = none.  The default 32 is UNMEASURED (no
-        # multi-GPU node was available in rounds 1-4): it costs the armed backward -- one micro-step in `accum` -- up to
-        # 12.5 % of its GEMM rate, against the alternative that a 256-workgroup launch finds a few CUs held by RCCL for
-        # the whole bucket and runs its last workgroups as a second wave (2x for that launch).  A/B on a node:
-        # SNX_EXCHANGE_RESERVED_CUS=0 / 16 / 32.
-        self.reserved_cus = int(os.environ.get("SNX_EXCHANGE_RESERVED_CUS", "32"))
+        # overlaps the backward (include/snx.h snx_set_reserved_cus).  OPT-IN (default 0 = none): no multi-GPU node was
+        # available in rounds 1-5, so whether a 224-workgroup launch (-12.5 % GEMM rate in the armed backward) beats a
+        # 256-workgroup launch that finds a few CUs held by RCCL is UNMEASURED.  A/B on a node:
+        # SNX_EXCHANGE_RESERVED_CUS=0 / 16 / 32.  A non-zero value changes the token partition of the weight-gradient
+        # GEMM (another fp32 summation tree): gradients then differ from the default's in the last bits.
+        self.reserved_cus = int(os.environ.get("SNX_EXCHANGE_RESERVED_CUS", "0"))
 
     def _note(self, *ev) -> None:
         if self.keep_log:

@@ -78,6 +78,40 @@ _Z3barv:
     with pytest.raises(A.AsmGuardError, match="scratch"):
         A.check_asm(asm, ["bar"])
     assert A.check_asm(asm, ["bar"], allow_scratch=True)["_Z3barv"]["scratch"] == 16
+
+
+def test_back_edges_are_followed_in_assembler_text():
+    """hipcc's loop labels (".LBB0_3:  ; =>This Inner Loop Header: Depth=1") must survive the splitter: a read at the
+    bottom of a loop whose retiring wait sits at the loop top, and a copy of its destination on the back-edge path."""
+    asm = """
+\t.text
+\t.globl\t_Z4loopv
+_Z4loopv:                               ; @_Z4loopv
+; %bb.0:
+\ts_mov_b32 s0, 0
+.LBB0_1:                                ; =>This Inner Loop Header: Depth=1
+\tv_accvgpr_write_b32 a9, v13
+\ts_waitcnt lgkmcnt(0)
+\tds_read_b128 v[12:15], v0
+\ts_add_i32 s0, s0, 1
+\ts_cmp_lt_i32 s0, 8
+\ts_cbranch_scc1 .LBB0_1
+; %bb.2:
+\ts_waitcnt lgkmcnt(0)
+\ts_endpgm
+.Lfunc_end0:
+\t.section\t.rodata
+\t.amdhsa_kernel _Z4loopv
+\t\t.amdhsa_private_segment_fixed_size 0
+\t.end_amdhsa_kernel
+"""
+    ks = A.kernels_of(asm)
+    assert ".LBB0_1:" in ks["_Z4loopv"]
+    with pytest.raises(A.AsmGuardError, match="touch the destination"):
+        A.check_asm(asm, ["loop"])
+    good = asm.replace("\tv_accvgpr_write_b32 a9, v13\n\ts_waitcnt lgkmcnt(0)\n",
+                       "\ts_waitcnt lgkmcnt(0)\n\tv_accvgpr_write_b32 a9, v13\n")
+    assert A.check_asm(good, ["loop"])["_Z4loopv"]["reads"] == 1
     with pytest.raises(A.AsmGuardError, match="no kernel matching"):
         A.check_asm(asm, ["nope"])
 
