@@ -197,16 +197,14 @@ int snx_nt256_configure(int32_t on, int32_t min_m);
 /* fp32 Wi [2I,C] -> bf16 interleaved copy out [2I,C] and/or its transpose out_t [C,2I]: every 64-row
  * group = [a rows 32q..32q+31 | g rows 32q..32q+31] (so a and its gate meet in one lane of the GEMM). */
 int snx_cast_geglu_interleave(const float* in, void* out, void* out_t, int32_t I, int32_t C, hipStream_t stream);
-/* weight gradient of a Linear: dW[N,K] += dY[M,N]^T X[M,K]  (N, K multiples of 128). */
-int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K, hipStream_t stream);
-/* same with dY's columns in the interleaved GeGLU order; dW rows land in the natural Wi order. */
-int snx_gemm_tn_accum_interleaved(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K,
-                                  hipStream_t stream);
-/* up to 4 weight-gradient problems over the SAME M token rows (the four Linears of one encoder layer, whose
- * nn.Linear backward torch runs as four GEMMs) in one launch.  From 8,192 token rows on: the 256x256 persistent kernel
- * (csrc/gemm_tn256.hip: one workgroup per CU, one flush of float atomics per workgroup); below, and for the ragged
- * rest of M % 64 rows: the concatenated 128x128 output tiles fill whole rounds of the resident workgroups
- * (csrc/gemm.hip).  N, K multiples of 128. */
+/* weight gradient of a Linear: dW[N,K] += dY[M,N]^T X[M,K]  (N, K multiples of 128).
+ * ORDERED REDUCTION (round 5; process switch "det_reduce", default 1): the token range is split over workgroups as
+ * before, but every workgroup stores its partial tile into the caller-owned workspace `ws` and a second small kernel adds
+ * a tile's partials to dW in a FIXED order -- two runs give the same bits, whatever order the workgroups finish in (the
+ * role of torch's deterministic cuBLAS reduction; the float-atomic flush of rounds 1-4 stays behind "det_reduce" = 0).
+ * `ws` needs snx_gemm_tn_workspace_bytes() bytes (0 for single-writer schedules; a bound that holds for every setting of
+ * the process switches), is scratch (no state between calls) and may be shared by launches on ONE stream; launches on
+ * different streams need workspaces of their own.  Missing or too small: SNX_E_ARG. */
 typedef struct snx_tn_problem {
   const void* dY; /* [M, N] bf16 */
   const void* X;  /* [M, K] bf16 */
@@ -215,18 +213,33 @@ typedef struct snx_tn_problem {
   int32_t interleaved; /* dY columns in the interleaved GeGLU order (N = 2I) */
   int32_t reserved;
 } snx_tn_problem;
-int snx_gemm_tn_accum_group(const snx_tn_problem* probs /*[host]*/, int32_t nprob, int32_t M, hipStream_t stream);
+size_t snx_gemm_tn_workspace_bytes(const snx_tn_problem* probs /*[host]; pointers unused*/, int32_t nprob, int32_t M);
+int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K, void* ws,
+                      size_t ws_bytes, hipStream_t stream);
+/* same with dY's columns in the interleaved GeGLU order; dW rows land in the natural Wi order. */
+int snx_gemm_tn_accum_interleaved(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K, void* ws,
+                                  size_t ws_bytes, hipStream_t stream);
+/* up to 4 weight-gradient problems over the SAME M token rows (the four Linears of one encoder layer, whose
+ * nn.Linear backward torch runs as four GEMMs) in one launch.  From 8,192 token rows on: the 256x256 persistent kernel
+ * (csrc/gemm_tn256.hip: one workgroup per CU, one flush per workgroup); below, and for the ragged
+ * rest of M % 64 rows: the concatenated 128x128 output tiles fill whole rounds of the resident workgroups
+ * (csrc/gemm.hip).  N, K multiples of 128. */
+int snx_gemm_tn_accum_group(const snx_tn_problem* probs /*[host]*/, int32_t nprob, int32_t M, void* ws, size_t ws_bytes,
+                            hipStream_t stream);
 /* Process-wide launch hint (host state, read at launch time): leave `n` CUs (0..128, rounded up to a multiple of 8)
  * to other kernels.  The persistent weight-gradient kernel takes one whole CU per workgroup; while RCCL's channel
  * workgroups run an overlapped gradient exchange (the role of DDP's reducer, ref:src/train/cli/train_v33_ddp.py:539-544)
  * a 256-workgroup launch would run its last workgroups as a second wave, so it launches 256 - n instead (its
- * schedule balances any count).  Results are unchanged up to fp32 summation order. */
+ * schedule balances any count).  The token partition changes with the count: results differ from the 256-workgroup
+ * launch's by fp32 summation order (each count is bit-reproducible by itself). */
 /* Process-wide switches of the library (csrc/config.h).  The library reads no environment variable; the Python binding
  * maps its SNX_* variables onto these keys once, at load time (snx/_lib.py), tests and tools call them directly.
  * Keys (default): nt256 (1; 0 off, 2 every eligible shape), nt256_min_m (8192), tn256 (1), tn256_min_m (8192),
  * dec256 (1), dec256_min_t (2048), bwd_overlap (1), side_prio (1), attn_streaming (0), attn_bwd_onepass (1),
  * splade_dh_panels (16), f32_gemm64 (0), f32_attn_rows (0), wcache_per_tensor (0), resid_in_ln (1: the Wo GEMMs store
- * bf16 and the residual add happens inside the following LayerNorm; 0: in the GEMMs' fp32 epilogue, same bits); diagnostics builds (-DSNX_DIAG) add
+ * bf16 and the residual add happens inside the following LayerNorm; 0: in the GEMMs' fp32 epilogue, same bits),
+ * det_reduce (1: weight gradients -- Linear dW, LayerNorm dw, embedding rows -- summed in a fixed order through the callers'
+ * workspaces, bit-reproducible; 0: float atomics in arrival order); diagnostics builds (-DSNX_DIAG) add
  * gemm_cg, gemm_dbg, gemm_mid, tn_splits, nt256_cg, nt256_dbg, nt256_force, tn256_tail_pct, tn256_dbg.  Unknown key or
  * value out of range: SNX_E_ARG. */
 int snx_configure(const char* key, int32_t value);
@@ -249,13 +262,20 @@ int snx_embed_ln_fwd(const int64_t* ids, const float* E, const float* w, float* 
 /* ModernBertPredictionHead tail (hf:489-490): LN(gelu(d)). */
 int snx_gelu_ln_fwd(const void* d, const float* w, void* x_out, int32_t T, int32_t H, float eps, hipStream_t stream);
 /* backward of the three above; dh (+)= dx, dw += ... (overwrite=1: dh = dx); dh_bf16 (nullable)
- * also receives bf16(dh), the gradient of the next bf16 branch output (saves a cast pass). */
+ * also receives bf16(dh), the gradient of the next bf16 branch output (saves a cast pass).
+ * `ws` (snx_ln_bwd_workspace_bytes / snx_embed_ln_bwd_workspace_bytes; scratch, one stream at a time): the blocks'
+ * partial dw rows, added to dw in block order by a second kernel; for the embeddings also the dx rows and the per-id
+ * token lists from which gradE[id] += sum_t dx[t] is formed in ascending token order (nn.Embedding's backward, hf:64-71,
+ * pad rows skipped).  With "det_reduce" = 0 `ws` may be NULL (float atomics, arrival order). */
+size_t snx_ln_bwd_workspace_bytes(int32_t T, int32_t H);
+size_t snx_embed_ln_bwd_workspace_bytes(int32_t T, int32_t H, int32_t V);
 int snx_ln_bwd(const void* dy, const float* h, const float* w, float* dh, void* dh_bf16, float* dw, int32_t T,
-               int32_t H, float eps, int32_t overwrite, hipStream_t stream);
+               int32_t H, float eps, int32_t overwrite, void* ws, size_t ws_bytes, hipStream_t stream);
 int snx_embed_ln_bwd(const float* dh, const int64_t* ids, const float* E, const float* w, float* gradE, float* dw,
-                     int32_t T, int32_t H, float eps, int32_t pad_id, hipStream_t stream);
+                     int32_t T, int32_t H, int32_t V, float eps, int32_t pad_id, void* ws, size_t ws_bytes,
+                     hipStream_t stream);
 int snx_gelu_ln_bwd(const void* dy, const void* d, const float* w, void* dd, float* dw, int32_t T, int32_t H,
-                    float eps, hipStream_t stream);
+                    float eps, void* ws, size_t ws_bytes, hipStream_t stream);
 
 /* apply_rotary_pos_emb (hf:196-219) in place on the q and k thirds of qkv [T,3,heads,64]. */
 int snx_rope_inplace(void* qkv, const float* cos_sin_tab, const int32_t* pos, int32_t T, int32_t heads,

@@ -22,6 +22,8 @@ struct SnxConfig {
   int wcache_per_tensor = 0;  // bf16 weight cache refreshed one launch per tensor
   int resid_in_ln = 1;        // forward: Wo GEMMs store bf16, the residual add happens inside the following LayerNorm
                               // (0: in the GEMM's fp32 epilogue; same bits, 0.17 ms per micro-step slower)
+  int det_reduce = 1;         // weight gradients reduced in a FIXED order (partial slabs in the caller's workspace + an
+                              // ordered reduction; bit-reproducible).  0: float atomics in arrival order (rounds 1-4; A/B)
 #ifdef SNX_DIAG
   int gemm_cg = -1;           // column-group width of the 128x128 NT tile order (-1: cost model)
   int gemm_dbg = 0;           // 1: L2-resident operands, 2: no epilogue

@@ -25,6 +25,7 @@ const Key KEYS[] = {
     {"f32_attn_rows", &SnxConfig::f32_attn_rows, 0, 1},
     {"wcache_per_tensor", &SnxConfig::wcache_per_tensor, 0, 1},
     {"resid_in_ln", &SnxConfig::resid_in_ln, 0, 1},
+    {"det_reduce", &SnxConfig::det_reduce, 0, 1},
 #ifdef SNX_DIAG
     {"gemm_cg", &SnxConfig::gemm_cg, -1, 64},
     {"gemm_dbg", &SnxConfig::gemm_dbg, 0, 3},

@@ -4,6 +4,7 @@
 // bf16 GELU and GeGLU product).  References: transformers modeling_modernbert.py:64-71
 // (embeddings), :89-91 (GeGLU), :196-219 (RoPE), :312-314,420,487 (LayerNorm), :489-490 (head).
 #include "common.h"
+#include "config.h"
 #include "snx.h"
 
 #define ROWS_PER_BLOCK 4   // 256 threads = 4 waves = 4 token rows
@@ -286,9 +287,12 @@ extern "C" int snx_gelu_ln_fwd(const void* d, const float* w, void* x_out, int32
 // LayerNorm backward.  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w,
 // dw[j] += sum_t dy[t,j] * xhat[t,j].  Each block walks `rows_per_block` rows with its 4 waves,
 // accumulating dw in registers (a lane owns the same columns for every row), reduces the 4
-// waves through LDS and issues one float atomic per column per block.
+// waves through LDS and stores the block's partial dw row into the caller's workspace; ln_dw_reduce_kernel then adds the
+// partial rows to dw in block order (FIXED order: bit-reproducible; "det_reduce" = 0: one float atomic per column per
+// block, arrival order, as in rounds 1-4).
 //   MODE 0: input h fp32;   dh[t] += dx                       (residual-stream LN)
-//   MODE 1: input E[ids[t]]; gradE[ids[t]] += dx (atomics, skip pad id)   (embedding LN)
+//   MODE 1: input E[ids[t]]; dx rows stored to dh[t] (fp32 scratch) for embed_scatter_kernel -- or, with "det_reduce" = 0,
+//           gradE[ids[t]] += dx by float atomics (skip pad id)                                  (embedding LN)
 //   MODE 2: input gelu(bf16 d); dd[t] = bf16(bf16(dx) * gelu'(d))          (head LN)
 //   MODE 3: input h fp32;   dh[t]  = dx  (overwrite: the final_norm, first op of backward)
 // ------------------------------------------------------------------------------------------
@@ -299,8 +303,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ w, float* __restrict__ dh,
                                                      bf16_t* __restrict__ dh_bf16,
                                                      float* __restrict__ gradE, bf16_t* __restrict__ dd,
-                                                     float* __restrict__ dw, int T, int H, float eps,
-                                                     int rows_per_block, int pad_id) {
+                                                     float* __restrict__ dw, float* __restrict__ dw_part, int T,
+                                                     int H, float eps, int rows_per_block, int pad_id) {
   __shared__ float red[ROWS_PER_BLOCK][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   RowVec<NV> wv, dwacc;
@@ -353,6 +357,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     } else if (MODE == 3) {
       g.store_f32(dh + (long)t * H, lane);
       if (dh_bf16) g.store_bf16(dh_bf16 + (long)t * H, lane);
+    } else if (MODE == 1 && dw_part) {
+      g.store_f32(dh + (long)t * H, lane);               // dx row; summed per vocabulary id, in token order, by embed_scatter_kernel
     } else if (MODE == 1) {
       // The row goes through this wave's slice of `red` so that every atomic instruction adds 64 CONSECUTIVE
       // floats (256 B: the shape the memory-side atomic units take at full rate) instead of 4 B at a 16-B stride.
@@ -380,8 +386,102 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   __syncthreads();
   for (int c = threadIdx.x; c < H; c += 256) {
     const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    atomicAdd(dw + c, s);
+    if (dw_part) dw_part[(long)blockIdx.x * H + c] = s;
+    else atomicAdd(dw + c, s);
   }
+}
+
+// dw[c] += part[0][c] + part[1][c] + ... in block order.  One 1024-thread workgroup per 64 columns: wave g sums the
+// contiguous run of partial rows [g nb / 16, (g + 1) nb / 16) (independent 256-byte loads, all in flight at once), the 16
+// wave sums are added in wave order through LDS.
+__global__ __launch_bounds__(1024) void ln_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nb,
+                                                            int H) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int b0 = (int)((long)g * nb / 16), b1 = (int)((long)(g + 1) * nb / 16);
+  float s = 0.f;
+  if (c < H)
+    for (int b = b0; b < b1; ++b) s += part[(long)b * H + c];
+  red[g][lane] = s;
+  __syncthreads();
+  if (g == 0 && c < H) {
+    float t = red[0][lane];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q][lane];
+    dw[c] += t;
+  }
+}
+
+// ---- embedding gradient in a FIXED order ---------------------------------------------------------------------------
+// gradE[id] += sum over the tokens t with ids[t] = id of dx[t], added in ascending t -- nn.Embedding's backward
+// (hf:64-71) as a segmented sum instead of T float atomics whose arrival order changes the last bits from run to run.
+// Per call: count the tokens of every id (integer atomics: exact), exclusive scan, fill the id's list in arrival order,
+// rank every token inside its id's list (its place in ascending-t order: sum over ids of n_id^2 comparisons -- tiny for
+// real batches, T^2 ~ a millisecond for a batch of one repeated id), then one wave per token: the FIRST token of an id
+// walks the sorted list and adds the rows.  Pad tokens take no part (padding_idx).
+__global__ void embed_count_kernel(const int64_t* __restrict__ ids, int* __restrict__ cnt, int T, int V, int pad_id) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const long id = ids[t];
+  if (id != pad_id && id >= 0 && id < V) atomicAdd(cnt + id, 1);
+}
+// off[v] = sum of cnt[0..v), off[V] = total; one workgroup, each thread a contiguous run of ids
+__global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int V) {
+  __shared__ int sums[1024];
+  const int per = (V + 1023) / 1024;
+  const int v0 = threadIdx.x * per, v1 = min(V, v0 + per);
+  int s = 0;
+  for (int v = v0; v < v1; ++v) s += cnt[v];
+  sums[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {                 // inclusive Hillis-Steele scan of the 1024 run sums
+    const int add = threadIdx.x >= d ? sums[threadIdx.x - d] : 0;
+    __syncthreads();
+    sums[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int run = threadIdx.x ? sums[threadIdx.x - 1] : 0;
+  for (int v = v0; v < v1; ++v) { off[v] = run; run += cnt[v]; }
+  if (threadIdx.x == 1023) off[V] = sums[1023];
+}
+__global__ void embed_fill_kernel(const int64_t* __restrict__ ids, const int* __restrict__ off, int* __restrict__ fill,
+                                  int* __restrict__ list, int T, int V, int pad_id) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const long id = ids[t];
+  if (id != pad_id && id >= 0 && id < V) list[off[id] + atomicAdd(fill + id, 1)] = t;
+}
+__global__ void embed_rank_kernel(const int64_t* __restrict__ ids, const int* __restrict__ off, const int* __restrict__ list,
+                                  int* __restrict__ sorted, int T, int V, int pad_id) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const long id = ids[t];
+  if (id == pad_id || id < 0 || id >= V) return;
+  const int b = off[id], e = off[id + 1];
+  int r = 0;
+  for (int j = b; j < e; ++j) r += list[j] < t;
+  sorted[b + r] = t;
+}
+template <int NV>
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids,
+                                                            const int* __restrict__ off, const int* __restrict__ sorted,
+                                                            float* __restrict__ gradE, int T, int H, int V, int pad_id) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const long id = ids[t];
+  if (id == pad_id || id < 0 || id >= V) return;
+  const int b = off[id], e = off[id + 1];
+  if (sorted[b] != t) return;                          // only the id's first token adds
+  RowVec<NV> acc, row;
+  acc.load_f32(gradE + id * (long)H, lane);
+  for (int j = b; j < e; ++j) {
+    row.load_f32(dx + (long)sorted[j] * H, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc.v[i] += row.v[i];
+  }
+  acc.store_f32(gradE + id * (long)H, lane);
 }
 
 static inline int ln_bwd_rows_per_block(int T) {
@@ -390,46 +490,101 @@ static inline int ln_bwd_rows_per_block(int T) {
   return rpb < ROWS_PER_BLOCK ? ROWS_PER_BLOCK : rpb;
 }
 
+// partial dw rows of one LayerNorm backward launch (one per block)
+extern "C" size_t snx_ln_bwd_workspace_bytes(int32_t T, int32_t H) {
+  if (T <= 0 || H <= 0) return 0;
+  return (size_t)cdiv(T, ln_bwd_rows_per_block(T)) * H * 4;
+}
+// + the dx rows and the per-id token lists of the embedding gradient's ordered sum
+extern "C" size_t snx_embed_ln_bwd_workspace_bytes(int32_t T, int32_t H, int32_t V) {
+  if (T <= 0 || H <= 0 || V <= 0) return 0;
+  const size_t a = (snx_ln_bwd_workspace_bytes(T, H) + 255) & ~(size_t)255;
+  const size_t rows = ((size_t)T * H * 4 + 255) & ~(size_t)255;
+  const size_t ints = ((size_t)(3 * (size_t)V + 1 + 2 * (size_t)T) * 4 + 255) & ~(size_t)255;
+  return a + rows + ints;
+}
+
+static int ln_dw_finish(float* part, float* dw, int nb, int H, hipStream_t st) {
+  hipLaunchKernelGGL(ln_dw_reduce_kernel, dim3(cdiv(H, 64)), dim3(1024), 0, st, (const float*)part, dw, nb, H);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
+}
+// the workspace of a launch: nullptr with "det_reduce" = 0 (float atomics); SNX_E_ARG if it is missing or too small
+#define LN_WS(need)                                              \
+  float* part = nullptr;                                         \
+  if (g_snx_cfg.det_reduce) {                                    \
+    if (!ws || ws_bytes < (need)) return SNX_E_ARG;              \
+    part = (float*)ws;                                           \
+  }
+
 extern "C" int snx_ln_bwd(const void* dy, const float* h, const float* w, float* dh, void* dh_bf16, float* dw,
-                          int32_t T, int32_t H, float eps, int32_t overwrite, hipStream_t st) {
+                          int32_t T, int32_t H, float eps, int32_t overwrite, void* ws, size_t ws_bytes,
+                          hipStream_t st) {
   if (!dy || !h || !w || !dh || !dw || T <= 0) return SNX_E_ARG;
   if (bad_h(H)) return SNX_E_SHAPE;
   const int rpb = ln_bwd_rows_per_block(T);
+  const int nb = cdiv(T, rpb);
+  LN_WS(snx_ln_bwd_workspace_bytes(T, H));
   if (overwrite) {
-    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 3>), dim3(cdiv(T, rpb)), dim3(256), 0, st,
+    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 3>), dim3(nb), dim3(256), 0, st,
                                       (const bf16_t*)dy, nullptr, h, nullptr, nullptr, nullptr, w, dh,
-                                      (bf16_t*)dh_bf16, nullptr, nullptr, dw, T, H, eps, rpb, -1));
+                                      (bf16_t*)dh_bf16, nullptr, nullptr, dw, part, T, H, eps, rpb, -1));
   } else {
-    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 0>), dim3(cdiv(T, rpb)), dim3(256), 0, st,
+    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 0>), dim3(nb), dim3(256), 0, st,
                                       (const bf16_t*)dy, nullptr, h, nullptr, nullptr, nullptr, w, dh,
-                                      (bf16_t*)dh_bf16, nullptr, nullptr, dw, T, H, eps, rpb, -1));
+                                      (bf16_t*)dh_bf16, nullptr, nullptr, dw, part, T, H, eps, rpb, -1));
   }
   SNX_CHECK_LAUNCH();
-  return SNX_OK;
+  return part ? ln_dw_finish(part, dw, nb, H, st) : SNX_OK;
 }
 
 extern "C" int snx_embed_ln_bwd(const float* dh, const int64_t* ids, const float* E, const float* w, float* gradE,
-                                float* dw, int32_t T, int32_t H, float eps, int32_t pad_id, hipStream_t st) {
-  if (!dh || !ids || !E || !w || !gradE || !dw || T <= 0) return SNX_E_ARG;
+                                float* dw, int32_t T, int32_t H, int32_t V, float eps, int32_t pad_id, void* ws,
+                                size_t ws_bytes, hipStream_t st) {
+  if (!dh || !ids || !E || !w || !gradE || !dw || T <= 0 || V <= 0) return SNX_E_ARG;
   if (bad_h(H)) return SNX_E_SHAPE;
   const int rpb = ln_bwd_rows_per_block(T);
-  DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 1>), dim3(cdiv(T, rpb)), dim3(256), 0, st, nullptr, dh,
-                                    nullptr, ids, E, nullptr, w, nullptr, nullptr, gradE, nullptr, dw, T, H, eps,
+  const int nb = cdiv(T, rpb);
+  LN_WS(snx_embed_ln_bwd_workspace_bytes(T, H, V));
+  float* dxrows = nullptr;
+  int *cnt = nullptr, *fill = nullptr, *off = nullptr, *list = nullptr, *sorted = nullptr;
+  if (part) {
+    char* base = (char*)ws;
+    size_t o = (snx_ln_bwd_workspace_bytes(T, H) + 255) & ~(size_t)255;
+    dxrows = (float*)(base + o);
+    o += ((size_t)T * H * 4 + 255) & ~(size_t)255;
+    cnt = (int*)(base + o); fill = cnt + V; off = fill + V; list = off + V + 1; sorted = list + T;
+    if (hipMemsetAsync(cnt, 0, (size_t)2 * V * 4, st) != hipSuccess) return SNX_E_ARG;
+    hipLaunchKernelGGL(embed_count_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, ids, cnt, T, V, pad_id);
+    hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)cnt, off, V);
+    hipLaunchKernelGGL(embed_fill_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, ids, (const int*)off, fill, list, T, V, pad_id);
+    hipLaunchKernelGGL(embed_rank_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, ids, (const int*)off, (const int*)list,
+                       sorted, T, V, pad_id);
+    SNX_CHECK_LAUNCH();
+  }
+  DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 1>), dim3(nb), dim3(256), 0, st, nullptr, dh,
+                                    nullptr, ids, E, nullptr, w, dxrows, nullptr, gradE, nullptr, dw, part, T, H, eps,
                                     rpb, pad_id));
   SNX_CHECK_LAUNCH();
-  return SNX_OK;
+  if (!part) return SNX_OK;
+  DISPATCH_NV(H, hipLaunchKernelGGL((embed_scatter_kernel<NV>), dim3(cdiv(T, 4)), dim3(256), 0, st, (const float*)dxrows,
+                                    ids, (const int*)off, (const int*)sorted, gradE, T, H, V, pad_id));
+  SNX_CHECK_LAUNCH();
+  return ln_dw_finish(part, dw, nb, H, st);
 }
 
 extern "C" int snx_gelu_ln_bwd(const void* dy, const void* d, const float* w, void* dd, float* dw, int32_t T,
-                               int32_t H, float eps, hipStream_t st) {
+                               int32_t H, float eps, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!dy || !d || !w || !dd || !dw || T <= 0) return SNX_E_ARG;
   if (bad_h(H)) return SNX_E_SHAPE;
   const int rpb = ln_bwd_rows_per_block(T);
-  DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 2>), dim3(cdiv(T, rpb)), dim3(256), 0, st,
+  const int nb = cdiv(T, rpb);
+  LN_WS(snx_ln_bwd_workspace_bytes(T, H));
+  DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 2>), dim3(nb), dim3(256), 0, st,
                                     (const bf16_t*)dy, nullptr, nullptr, nullptr, nullptr, (const bf16_t*)d, w,
-                                    nullptr, nullptr, nullptr, (bf16_t*)dd, dw, T, H, eps, rpb, -1));
+                                    nullptr, nullptr, nullptr, (bf16_t*)dd, dw, part, T, H, eps, rpb, -1));
   SNX_CHECK_LAUNCH();
-  return SNX_OK;
+  return part ? ln_dw_finish(part, dw, nb, H, st) : SNX_OK;
 }
 
 // ------------------------------------------------------------------------------------------

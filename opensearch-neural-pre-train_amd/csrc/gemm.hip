@@ -377,7 +377,13 @@ __device__ __forceinline__ void tn_stage(const bf16_t* __restrict__ G, long ld, 
   }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnGroup grp, int M, int ntiles, int rows_per_split) {
+// flush modes of the token-split kernel below: TN_ATOMIC = float atomics into dW (arrival order; "det_reduce" = 0),
+// TN_DIRECT = plain dW += acc (ONE split: a single writer per element), TN_SLAB = plain store of the partial into slab
+// (split, tile) of the caller's workspace, added to dW in split order by tn128_reduce_kernel
+enum { TN_ATOMIC = 0, TN_DIRECT = 1, TN_SLAB = 2 };
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnGroup grp, int M, int ntiles, int rows_per_split, int mode,
+                                                         float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE_BYTES = 64 * 256, STAGE_BYTES = 2 * TILE_BYTES;
   const int lane = threadIdx.x & 63;
@@ -388,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnGroup grp, int M, int
   // from HBM by one XCD only (measured before: 4x the algorithmic bytes, ~5 TB/s of fabric traffic).
   const int work = xcd_remap(blockIdx.x, gridDim.x);
   int tile_id = work % ntiles;
+  const int tile_global = tile_id;
   const int split = work / ntiles;
   int p = 0;
 #pragma unroll
@@ -448,6 +455,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnGroup grp, int M, int
 #endif
   }
   // acc[i][j][r] = dW[n0 + wm*64 + i*16 + 4g + r][k0 + wn*64 + j*16 + (lane&15)]
+  if (mode == TN_SLAB) {
+    float* slab = ws + ((size_t)split * ntiles + tile_global) * (128 * 128);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nl = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) slab[nl * 128 + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -458,9 +477,38 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnGroup grp, int M, int
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k = k0 + wn * 64 + j * 16 + (lane & 15);
-        atomicAdd(dW + (long)n * K + k, acc[i][j][r]);
+        if (mode == TN_ATOMIC) atomicAdd(dW + (long)n * K + k, acc[i][j][r]);
+        else dW[(long)n * K + k] += acc[i][j][r];
       }
     }
+}
+
+// dW tile += slab(split 0) + slab(split 1) + ...: the FIXED order that makes the token-split weight gradient
+// bit-reproducible.  One workgroup per (tile, 32-row chunk), a thread owns 4 consecutive k of 4 rows.
+__global__ __launch_bounds__(256) void tn128_reduce_kernel(TnGroup grp, int ntiles, int splits, const float* __restrict__ ws) {
+  int tile_id = blockIdx.x;
+  const int tile_global = tile_id;
+  int p = 0;
+#pragma unroll
+  for (int q = 0; q < SNX_TN_MAX_GROUP - 1; ++q)
+    if (q + 1 < grp.nprob && tile_id >= grp.tile_end[q]) p = q + 1;
+  if (p > 0) tile_id -= grp.tile_end[p - 1];
+  float* __restrict__ dW = grp.dW[p];
+  const int K = grp.K[p], interleave_I = grp.inter[p];
+  const int tiles_k = K / 128;
+  const int n0 = (tile_id / tiles_k) * 128, k0 = (tile_id % tiles_k) * 128;
+  const int col = (threadIdx.x & 31) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int nl = blockIdx.y * 32 + q * 8 + (threadIdx.x >> 5);
+    int n = n0 + nl;
+    if (interleave_I > 0) n = ((n & 63) < 32) ? 32 * (n >> 6) + (n & 31) : interleave_I + 32 * (n >> 6) + (n & 31);
+    float* dst = dW + (long)n * K + k0 + col;
+    f32x4 a = *(const f32x4*)dst;
+    const float* src = ws + (size_t)tile_global * (128 * 128) + nl * 128 + col;
+    for (int sp = 0; sp < splits; ++sp) a += *(const f32x4*)(src + (size_t)sp * ntiles * (128 * 128));
+    *(f32x4*)dst = a;
+  }
 }
 
 // splits of the token range: whole rounds of the 512 resident workgroup slots (2 x 64 KiB LDS per CU on 256
@@ -480,13 +528,34 @@ static int tn_pick_splits(int tiles, int M) {
   return best;
 }
 
-static int launch_tn_group(const TnGroup& g, int M, hipStream_t st) {
+// token splits and rows per split of the 128x128 kernel for a group of `tiles` output tiles
+static void tn128_plan(int tiles, int M, int& splits, int& rows) {
+  splits = tn_pick_splits(tiles, M);
+  rows = cdiv(M, splits);
+  rows = ((rows + 63) / 64) * 64;
+  splits = cdiv(M, rows);
+}
+
+// Bytes of partial slabs the ordered reduction of this group may need: the maximum over the process switches that
+// change the schedule ("tn256", "tn256_min_m", the reserved CUs), so that a workspace sized once stays large enough when a
+// test or an A/B flips one of them.
+static size_t tn_group_ws_bytes(const TnGroup& g, int M) {
+  size_t need = snx_tn256_ws_bound(g, M & ~63);
+  const int tiles = g.tile_end[g.nprob - 1];
+  int splits, rows;
+  tn128_plan(tiles, M, splits, rows);
+  if (splits > 1) need = max(need, (size_t)splits * tiles * (128 * 128 * 4));
+  return need;
+}
+
+static int launch_tn_group(const TnGroup& g, int M, void* ws, size_t ws_bytes, hipStream_t st) {
+  const bool det = g_snx_cfg.det_reduce != 0;
   // long token ranges: the 256x256 persistent form (gemm_tn256.hip); "tn256" = 0 keeps the 128x128 kernel
   const int tn256 = g_snx_cfg.tn256, tn256_min_m = g_snx_cfg.tn256_min_m;
   if (tn256 && M >= tn256_min_m) {
     // whole 64-row K-steps there; a ragged rest of the token range (< 64 rows) comes back to this kernel
     const int M64 = M & ~63;
-    const int rc = snx_launch_tn256(g, M64, st);
+    const int rc = snx_launch_tn256(g, M64, ws, ws_bytes, st);
     if (rc == SNX_OK) {
       if (M64 == M) return SNX_OK;
       TnGroup rest = g;
@@ -495,42 +564,51 @@ static int launch_tn_group(const TnGroup& g, int M, hipStream_t st) {
         rest.X[p] = g.X[p] + (long)M64 * g.K[p];
       }
       const int tiles = g.tile_end[g.nprob - 1];
-      hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles), dim3(256), 2 * 2 * 64 * 256, st, rest, M - M64, tiles, 64);
+      // one split: a single writer per element, behind the reduction above in stream order
+      hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles), dim3(256), 2 * 2 * 64 * 256, st, rest, M - M64, tiles, 64,
+                         det ? TN_DIRECT : TN_ATOMIC, (float*)nullptr);
       SNX_CHECK_LAUNCH();
       return SNX_OK;
     }
     if (rc != SNX_E_SHAPE) return rc;                 // groups it does not take (> 256 tiles): fall through
   }
   const int tiles = g.tile_end[g.nprob - 1];
-  int splits = tn_pick_splits(tiles, M);
-  int rows = cdiv(M, splits);
-  rows = ((rows + 63) / 64) * 64;
-  splits = cdiv(M, rows);
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 2 * 2 * 64 * 256, st, g, M, tiles, rows);
+  int splits, rows;
+  tn128_plan(tiles, M, splits, rows);
+  int mode = TN_ATOMIC;
+  if (det) {
+    mode = splits > 1 ? TN_SLAB : TN_DIRECT;
+    if (mode == TN_SLAB && (!ws || ws_bytes < (size_t)splits * tiles * (128 * 128 * 4))) return SNX_E_ARG;
+  }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 2 * 2 * 64 * 256, st, g, M, tiles, rows, mode,
+                     (float*)ws);
   SNX_CHECK_LAUNCH();
+  if (mode == TN_SLAB) {
+    hipLaunchKernelGGL(tn128_reduce_kernel, dim3(tiles, 4), dim3(256), 0, st, g, tiles, splits, (const float*)ws);
+    SNX_CHECK_LAUNCH();
+  }
   return SNX_OK;
 }
 
-static int launch_tn(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K, int interleave_I,
-                     hipStream_t st) {
+static int tn_one(TnGroup& g, const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K, int interleave_I) {
   if (!dY || !X || !dW) return SNX_E_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128)) return SNX_E_SHAPE;
   if (interleave_I < 0 || (interleave_I > 0 && 2 * interleave_I != N)) return SNX_E_SHAPE;
-  TnGroup g{};
+  g = TnGroup{};
   g.dY[0] = (const bf16_t*)dY; g.X[0] = (const bf16_t*)X; g.dW[0] = dW;
   g.N[0] = N; g.K[0] = K; g.inter[0] = interleave_I;
   g.tile_end[0] = (N / 128) * (K / 128);
   g.nprob = 1;
-  return launch_tn_group(g, M, st);
+  return SNX_OK;
 }
 
-extern "C" int snx_gemm_tn_accum_group(const snx_tn_problem* probs, int32_t nprob, int32_t M, hipStream_t st) {
+static int tn_group(TnGroup& g, const snx_tn_problem* probs, int32_t nprob, int32_t M, bool need_ptrs) {
   if (!probs || nprob < 1 || nprob > SNX_TN_MAX_GROUP || M <= 0) return SNX_E_ARG;
-  TnGroup g{};
+  g = TnGroup{};
   int run = 0;
   for (int p = 0; p < nprob; ++p) {
     const snx_tn_problem& q = probs[p];
-    if (!q.dY || !q.X || !q.dW) return SNX_E_ARG;
+    if (need_ptrs && (!q.dY || !q.X || !q.dW)) return SNX_E_ARG;
     if (q.N <= 0 || q.K <= 0 || (q.N % 128) || (q.K % 128)) return SNX_E_SHAPE;
     g.dY[p] = (const bf16_t*)q.dY; g.X[p] = (const bf16_t*)q.X; g.dW[p] = q.dW;
     g.N[p] = q.N; g.K[p] = q.K; g.inter[p] = q.interleaved ? q.N / 2 : 0;
@@ -538,16 +616,33 @@ extern "C" int snx_gemm_tn_accum_group(const snx_tn_problem* probs, int32_t npro
     g.tile_end[p] = run;
   }
   g.nprob = nprob;
-  return launch_tn_group(g, M, st);
+  return SNX_OK;
 }
 
-extern "C" int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K,
-                                 hipStream_t st) {
-  return launch_tn(dY, X, dW, M, N, K, 0, st);
+extern "C" size_t snx_gemm_tn_workspace_bytes(const snx_tn_problem* probs, int32_t nprob, int32_t M) {
+  TnGroup g;
+  if (tn_group(g, probs, nprob, M, false) != SNX_OK) return 0;
+  return tn_group_ws_bytes(g, M);
+}
+
+extern "C" int snx_gemm_tn_accum_group(const snx_tn_problem* probs, int32_t nprob, int32_t M, void* ws, size_t ws_bytes,
+                                       hipStream_t st) {
+  TnGroup g;
+  if (const int rc = tn_group(g, probs, nprob, M, true)) return rc;
+  return launch_tn_group(g, M, ws, ws_bytes, st);
+}
+
+extern "C" int snx_gemm_tn_accum(const void* dY, const void* X, float* dW, int32_t M, int32_t N, int32_t K, void* ws,
+                                 size_t ws_bytes, hipStream_t st) {
+  TnGroup g;
+  if (const int rc = tn_one(g, dY, X, dW, M, N, K, 0)) return rc;
+  return launch_tn_group(g, M, ws, ws_bytes, st);
 }
 
 // dY [M, 2I] in the interleaved GeGLU column order -> dW rows in the natural Wi order
 extern "C" int snx_gemm_tn_accum_interleaved(const void* dY, const void* X, float* dW, int32_t M, int32_t N,
-                                             int32_t K, hipStream_t st) {
-  return launch_tn(dY, X, dW, M, N, K, N / 2, st);
+                                             int32_t K, void* ws, size_t ws_bytes, hipStream_t st) {
+  TnGroup g;
+  if (const int rc = tn_one(g, dY, X, dW, M, N, K, N / 2)) return rc;
+  return launch_tn_group(g, M, ws, ws_bytes, st);
 }

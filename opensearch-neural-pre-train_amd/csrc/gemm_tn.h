@@ -36,5 +36,8 @@ struct TnGroup {
 
 
 // 256x256 persistent form (gemm_tn256.hip): SNX_OK, SNX_E_SHAPE when it does not take the group (more than 256
-// tiles), or a HIP error code.  M % 64 == 0.
-int snx_launch_tn256(const TnGroup& g, int M, hipStream_t st);
+// tiles), SNX_E_ARG when the ordered reduction ("det_reduce", default) finds `ws` missing or smaller than
+// snx_tn256_ws_bytes(), or a HIP error code.  M % 64 == 0.
+int snx_launch_tn256(const TnGroup& g, int M, void* ws, size_t ws_bytes, hipStream_t st);
+size_t snx_tn256_ws_bytes(const TnGroup& g, int M);    // with the CUs reserved right now
+size_t snx_tn256_ws_bound(const TnGroup& g, int M);    // maximum over every reservation (0..128)

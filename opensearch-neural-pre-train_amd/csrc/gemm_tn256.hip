@@ -27,10 +27,14 @@
 // no division in it (the item schedule is advanced once per item); three copies of the body at most (a fourth and
 // the register allocator spills).
 //
-// Work split (no inter-workgroup dependency; float atomics do the reduction, as in gemm.hip): with n output tiles in
-// the group, P = floor(256 / n) token pieces; workgroup (piece p, tile t) runs ONE long item and flushes its
-// accumulators once (an XCD-segment split tried first flushed three times per workgroup: 188 MB of atomics and
-// 90 us per launch).  The 256 - P*n remaining workgroups share the last `tail_len` K-steps of the token range over
+// Work split (no inter-workgroup dependency): with n output tiles in the group, P = floor(256 / n) token pieces;
+// workgroup (piece p, tile t) runs ONE long item and flushes its accumulators once (an XCD-segment split tried first
+// flushed three times per workgroup: 188 MB of atomics and 90 us per launch).  ORDERED REDUCTION (round 5): a flush is a
+// plain store of the 256 x 256 fp32 partial into slab (contributor c, tile t) of a caller-owned workspace, and a second
+// small kernel (tn256_reduce_kernel) adds a tile's slabs to dW in the FIXED order c = 0, 1, ... (pieces by token range,
+// then the tail workgroups by id): the weight gradients are bit-reproducible from run to run, whatever order the
+// workgroups finish in.  Rounds 2-4 flushed with float atomics (order = arrival order: two runs differed in the last
+// bits); that form stays behind snx_configure("det_reduce", 0) for A/B.  The 256 - P*n remaining workgroups share the last `tail_len` K-steps of the token range over
 // all tiles, stream-K fashion (contiguous (tile, K-step) ranges), so that every workgroup multiplies about
 // n * steps / 256 K-steps.  Logical workgroup ids are XCD-contiguous (blockIdx & 7 = XCD): an XCD's 32 workgroups
 // are neighbouring tiles of the same token piece and walk it in step, sharing dY / X rows through their L2.
@@ -71,7 +75,21 @@ struct Sched {
   int P, nmain, main_len;            // pieces; P * ntiles one-item workgroups over K-steps [0, main_len)
   int tail_len, tail_u;              // K-steps [main_len, nsteps): tail_u (tile, K-step) units per tail workgroup
   int dbg;
+  float* ws;                         // partial slabs [contributor][tile][256][256] fp32 (nullptr: float atomics into dW)
 };
+
+// contributor index of logical workgroup L for output tile `tile`: pieces 0..P-1, then the tail workgroups that touch
+// the tile in ascending id (the first of them is the one whose unit range contains the tile's first tail unit)
+__device__ __host__ __forceinline__ int contributor_of(const Sched& s, int L, int tile) {
+  if (L < s.nmain) return L / s.ntiles;
+  return s.P + (L - s.nmain) - (tile * s.tail_len) / s.tail_u;
+}
+// number of slabs tile `tile` owns (main pieces that are empty -- fewer K-steps than pieces -- write nothing and are
+// skipped by the reduction through the same sb < se test)
+__device__ __host__ __forceinline__ int tail_contributors(const Sched& s, int tile) {
+  if (s.tail_len <= 0) return 0;
+  return ((tile + 1) * s.tail_len - 1) / s.tail_u - (tile * s.tail_len) / s.tail_u + 1;
+}
 
 // item `it` of logical workgroup L
 __device__ __forceinline__ bool item_at(const Sched& s, int L, int it, Item& o) {
@@ -208,7 +226,9 @@ extern "C" int snx_tn256_trace_set(void* buf) {
 }
 #endif
 
-template <bool NODMA>
+// SLAB: the flush stores the partial tile into the workspace (ordered reduction); otherwise float atomics into dW.  A
+// template parameter, not a branch: with both flush forms in one kernel hipcc spills 660 bytes per lane.
+template <bool NODMA, bool SLAB>
 __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sched sch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -321,6 +341,31 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
       asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // MFMA results -> VALU reads: the asm MFMAs are opaque to the hazard pass
       const bool whole = cp_tile.n0 + 256 <= cp_tile.N && cp_tile.k0 + TK <= cp_tile.K;
       if (!(sch.dbg & 1)) {
+        if (SLAB) {
+          // plain stores of the whole 256 x 256 partial (columns / rows outside the matrix included: they stay inside the
+          // slab and the reduction never reads them) in the tile's natural [n][k] order
+          // Addressing: ONE per-lane 32-bit offset for all 64 stores + a wave-uniform (scalar) row base per store, so that
+          // the flush needs no 64-bit address registers: the fragments of the next item are already live in VGPRs here,
+          // and per-store address pairs made hipcc spill them to scratch around the flush.
+          float* slab = sch.ws + ((size_t)contributor_of(sch, L, cp_item.tile) * sch.ntiles + cp_item.tile) * (256 * 256) +
+                        (wm * 128) * 256 + wn * 128;
+          const unsigned lo = (unsigned)(4 * (lane >> 5) * 256 + (lane & 31));
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+              // The accumulator element is read out of its AGPR by hand, one volatile asm per store: left to itself hipcc
+              // copies whole 16-register accumulator tuples into VGPRs ahead of the stores (several tuples at once, whatever
+              // the stores' order or volatility) and spills ~300 bytes per lane around the flush.
+              float* row = slab + (i * 32 + 8 * (v >> 2) + (v & 3)) * 256;   // uniform
+#pragma unroll
+              for (int j = 0; j < NJ; ++j) {
+                float x;
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[i][j][v]));
+                row[j * 32 + lo] = x;
+              }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -340,6 +385,7 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
                 if (nok && k + j * 32 < cp_tile.K) atomicAdd(row + j * 32, acc[i][j][v]);
             }
           }
+        }
       }
       if (!cp_has_next) break;
       first = true;
@@ -362,10 +408,40 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
 #endif
 }
 
+// ---- ordered reduction of the partial slabs -------------------------------------------------------------------------
+// dW tile += slab(0) + slab(1) + ... in contributor order (see contributor_of).  One workgroup per (tile, 32-row
+// chunk); a thread owns 4 consecutive k of 8 rows: every access is a whole 16-byte piece of a 1-KiB row.  The slabs were
+// written a moment ago by the GEMM kernel (the group's 60-100 MB sit in the 256-MiB Infinity Cache).
+__global__ __launch_bounds__(256) void tn256_reduce_kernel(TnGroup grp, Sched sch) {
+  const int tile = blockIdx.x, chunk = blockIdx.y;
+  const Tile t = decode(grp, tile);
+  const int col = (threadIdx.x & 63) * 4;
+  const int k = t.k0 + col;
+  if (k >= t.K) return;                               // K % 128 == 0: a 16-byte piece lies wholly inside or outside
+  const int ntail = tail_contributors(sch, tile);
+  const size_t tile_stride = (size_t)sch.ntiles * (256 * 256);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int nl = chunk * 32 + q * 4 + (threadIdx.x >> 6);
+    int n = t.n0 + nl;
+    if (n >= t.N) continue;
+    if (t.inter > 0) n = ((n & 63) < 32) ? 32 * (n >> 6) + (n & 31) : t.inter + 32 * (n >> 6) + (n & 31);
+    float* dst = t.dw + (long)n * t.K + k;
+    f32x4 a = *(const f32x4*)dst;
+    const float* src = sch.ws + (size_t)tile * (256 * 256) + nl * 256 + col;
+    for (int p = 0; p < sch.P; ++p) {
+      if (p * sch.main_len / sch.P < (p + 1) * sch.main_len / sch.P) a += *(const f32x4*)(src + p * tile_stride);
+    }
+    for (int c = 0; c < ntail; ++c) a += *(const f32x4*)(src + (sch.P + c) * tile_stride);
+    *(f32x4*)dst = a;
+  }
+}
+
 // CUs left to other kernels (RCCL's channel workgroups while a gradient bucket is being exchanged): this kernel's
 // workgroups take a whole CU each (160 KiB of LDS, one 512-register wave per SIMD), so with fewer than 256 free CUs
 // a 256-workgroup launch would run its last workgroups as a second wave -- twice the time.  The schedule below
-// balances any workgroup count (one long item per workgroup + a stream-K tail), so the launch simply shrinks.
+// balances any workgroup count (one long item per workgroup + a stream-K tail), so the launch simply shrinks -- and
+// with it the token partition: another fp32 summation tree, i.e. last-bit differences against the 256-workgroup result.
 static int g_reserved_cus = 0;
 extern "C" int snx_set_reserved_cus(int32_t n) {
   if (n < 0 || n > 128) return SNX_E_ARG;
@@ -374,44 +450,79 @@ extern "C" int snx_set_reserved_cus(int32_t n) {
 }
 extern "C" int snx_get_reserved_cus() { return g_reserved_cus; }
 
-int snx_launch_tn256(const TnGroup& g128, int M, hipStream_t st) {
-  const int NWG = ::NWG - g_reserved_cus;
-  TnGroup g = g128;
+// schedule of a group over M token rows on `nwg` workgroups; false: the kernel does not take it
+static bool tn256_schedule(TnGroup& g, int M, int nwg, Sched& s, int& max_slabs) {
   int run = 0;
   for (int p = 0; p < g.nprob; ++p) {
     run += cdiv(g.N[p], 256) * cdiv(g.K[p], TK);
     g.tile_end[p] = run;
   }
-  if (run > NWG || M >= (1 << 27)) return SNX_E_SHAPE;   // caller falls back to the 128x128 kernel
-  Sched s;
+  if (run > nwg || M >= (1 << 27)) return false;
   s.ntiles = run;
   s.nsteps = cdiv(M, 2 * HS);
-  s.P = NWG / run;
+  s.P = nwg / run;
   s.nmain = s.P * run;
-  const int wt = NWG - s.nmain;
+  const int wt = nwg - s.nmain;
   // every workgroup should multiply about ntiles * nsteps / 256 half-steps; the tail workgroups flush once per tile
   // they touch, which SNX_TN256_TAIL_PCT (default 95) takes off their share
   const int tail_pct = SNX_DIAG_CFG(tn256_tail_pct, 95);
-  s.tail_len = wt > 0 ? (int)((long)s.nsteps * wt * tail_pct / (100L * NWG)) : 0;
+  s.tail_len = wt > 0 ? (int)((long)s.nsteps * wt * tail_pct / (100L * nwg)) : 0;
   s.main_len = s.nsteps - s.tail_len;
   s.tail_u = wt > 0 ? cdiv((long)s.ntiles * s.tail_len, wt) : 0;
-  // diagnostics: 1 = no atomics, 2 = no DMA, 4 = L2-resident operands
+  if (s.tail_u <= 0) s.tail_len = 0, s.main_len = s.nsteps;
+  s.dbg = 0;
+  s.ws = nullptr;
+  int mt = 0;
+  for (int t = 0; t < s.ntiles; ++t) mt = max(mt, tail_contributors(s, t));
+  max_slabs = s.P + mt;
+  return true;
+}
+
+// bytes of partial slabs the ordered reduction of this group needs (0: the 128x128 kernel takes the group)
+size_t snx_tn256_ws_bytes(const TnGroup& g128, int M) {
+  TnGroup g = g128;
+  Sched s;
+  int slabs = 0;
+  if (!tn256_schedule(g, M, ::NWG - g_reserved_cus, s, slabs)) return 0;
+  return (size_t)slabs * s.ntiles * (256 * 256 * 4);
+}
+
+size_t snx_tn256_ws_bound(const TnGroup& g128, int M) {
+  size_t need = 0;
+  if (M < 64) return 0;
+  for (int r = 0; r <= 128; r += 8) {
+    TnGroup g = g128;
+    Sched s;
+    int slabs = 0;
+    if (tn256_schedule(g, M, ::NWG - r, s, slabs)) need = max(need, (size_t)slabs * s.ntiles * (256 * 256 * 4));
+  }
+  return need;
+}
+
+int snx_launch_tn256(const TnGroup& g128, int M, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int NWG = ::NWG - g_reserved_cus;
+  TnGroup g = g128;
+  Sched s;
+  int slabs = 0;
+  if (!tn256_schedule(g, M, NWG, s, slabs)) return SNX_E_SHAPE;   // caller falls back to the 128x128 kernel
+  // diagnostics: 1 = no flush, 2 = no DMA, 4 = L2-resident operands
   const int dbg = SNX_DIAG_CFG(tn256_dbg, 0);
   s.dbg = dbg;
-  static bool attr[64] = {};                          // per device: the 160 KiB dynamic-LDS opt-in
-  int devid = 0;
-  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return SNX_E_ARG;
-  if (!attr[devid]) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, RING * SLOT);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              RING * SLOT);
-    if (e != hipSuccess) return (int)e;
-    attr[devid] = true;
+  if (g_snx_cfg.det_reduce) {
+    if (!ws || ws_bytes < (size_t)slabs * s.ntiles * (256 * 256 * 4)) return SNX_E_ARG;
+    s.ws = (float*)ws;
   }
-  if (dbg & 2) hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(NWG), dim3(256), RING * SLOT, st, g, M, s);
-  else hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(NWG), dim3(256), RING * SLOT, st, g, M, s);
+  static LdsOptIn optin[4];
+  void (*kern)(TnGroup, int, Sched);
+  int which;
+  if (s.ws) { which = (dbg & 2) ? 3 : 2; kern = (dbg & 2) ? gemm_tn256_kernel<true, true> : gemm_tn256_kernel<false, true>; }
+  else { which = (dbg & 2) ? 1 : 0; kern = (dbg & 2) ? gemm_tn256_kernel<true, false> : gemm_tn256_kernel<false, false>; }
+  if (const int rc = optin[which].ensure((const void*)kern, RING * SLOT)) return rc;
+  hipLaunchKernelGGL(kern, dim3(NWG), dim3(256), RING * SLOT, st, g, M, s);
   SNX_CHECK_LAUNCH();
+  if (s.ws && !(dbg & 1)) {
+    hipLaunchKernelGGL(tn256_reduce_kernel, dim3(s.ntiles, 8), dim3(256), 0, st, g, s);
+    SNX_CHECK_LAUNCH();
+  }
   return SNX_OK;
 }

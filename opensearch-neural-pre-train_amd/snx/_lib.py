@@ -25,14 +25,17 @@ SIGNATURES = {
     "snx_cast_transpose_bf16": (I32, [P, P, I32, I32, P]),
     "snx_gemm_nt_bf16": (I32, [P, P, P, I32, I32, I32, P]),
     "snx_gemm_nt_resid": (I32, [P, P, P, P, I32, I32, I32, P]),
-    "snx_gemm_tn_accum": (I32, [P, P, P, I32, I32, I32, P]),
+    "snx_gemm_tn_accum": (I32, [P, P, P, I32, I32, I32, P, SZ, P]),
+    "snx_gemm_tn_workspace_bytes": (SZ, [P, I32, I32]),
     "snx_ln_fwd": (I32, [P, P, P, I32, I32, F32, P]),
     "snx_ln_fwd_add": (I32, [P, P, P, P, P, I32, I32, F32, P]),
     "snx_embed_ln_fwd": (I32, [P, P, P, P, P, I32, I32, F32, P]),
     "snx_gelu_ln_fwd": (I32, [P, P, P, I32, I32, F32, P]),
-    "snx_ln_bwd": (I32, [P, P, P, P, P, P, I32, I32, F32, I32, P]),
-    "snx_embed_ln_bwd": (I32, [P, P, P, P, P, P, I32, I32, F32, I32, P]),
-    "snx_gelu_ln_bwd": (I32, [P, P, P, P, P, I32, I32, F32, P]),
+    "snx_ln_bwd": (I32, [P, P, P, P, P, P, I32, I32, F32, I32, P, SZ, P]),
+    "snx_ln_bwd_workspace_bytes": (SZ, [I32, I32]),
+    "snx_embed_ln_bwd_workspace_bytes": (SZ, [I32, I32, I32]),
+    "snx_embed_ln_bwd": (I32, [P, P, P, P, P, P, I32, I32, I32, F32, I32, P, SZ, P]),
+    "snx_gelu_ln_bwd": (I32, [P, P, P, P, P, I32, I32, F32, P, SZ, P]),
     "snx_rope_inplace": (I32, [P, P, P, I32, I32, I32, P]),
     "snx_geglu_fwd": (I32, [P, P, I32, I32, P]),
     "snx_geglu_bwd": (I32, [P, P, P, I32, I32, P]),
@@ -49,8 +52,8 @@ SIGNATURES = {
     "snx_gemm_nt_rope_rows": (I32, [P, P, P, P, P, P, I32, I32, I32, I32, P]),
     "snx_gemm_nt_geglu_fwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "snx_gemm_nt_geglu_bwd": (I32, [P, P, P, P, I32, I32, I32, P]),
-    "snx_gemm_tn_accum_interleaved": (I32, [P, P, P, I32, I32, I32, P]),
-    "snx_gemm_tn_accum_group": (I32, [P, I32, I32, P]),
+    "snx_gemm_tn_accum_interleaved": (I32, [P, P, P, I32, I32, I32, P, SZ, P]),
+    "snx_gemm_tn_accum_group": (I32, [P, I32, I32, P, SZ, P]),
     "snx_nt256_configure": (I32, [I32, I32]),
     "snx_set_reserved_cus": (I32, [I32]),
     "snx_get_reserved_cus": (I32, []),

@@ -77,6 +77,23 @@ def gemm_nt_resid(a: torch.Tensor, b: torch.Tensor, h_in: torch.Tensor) -> torch
     return h_out
 
 
+class TnProblem(C.Structure):
+    _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32),
+                ("interleaved", C.c_int32), ("reserved", C.c_int32)]
+
+
+def _scratch(nbytes: int, device) -> Tuple[Optional[torch.Tensor], int]:
+    """Caller-owned workspace of an ordered reduction (include/snx.h "det_reduce"): a fresh torch buffer per call -- the
+    caching allocator hands it back stream-ordered, which is the one-stream-at-a-time rule of the header."""
+    if nbytes <= 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+def _tn_ws(arr, n: int, M: int, device):
+    return _scratch(int(fn("snx_gemm_tn_workspace_bytes")(arr, n, M)), device)
+
+
 def gemm_tn_accum(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor) -> None:
     """dw[N,K] += dy[M,N]^T @ x[M,K]  (fp32 accumulate into the gradient buffer)."""
     _chk(dy, BF16, "dy"); _chk(x, BF16, "x")
@@ -85,7 +102,9 @@ def gemm_tn_accum(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor) -> None:
     if M != M2:
         raise ValueError("gemm_tn_accum: row mismatch")
     _chk(dw, torch.float32, "dw", (N, K))
-    check(fn("snx_gemm_tn_accum")(_p(dy), _p(x), _p(dw), M, N, K, _stream()), "snx_gemm_tn_accum")
+    one = (TnProblem * 1)(TnProblem(0, 0, 0, N, K, 0, 0))
+    ws, nb = _tn_ws(one, 1, M, dy.device)
+    check(fn("snx_gemm_tn_accum")(_p(dy), _p(x), _p(dw), M, N, K, _p(ws), nb, _stream()), "snx_gemm_tn_accum")
 
 
 def gemm_nt_rope(a: torch.Tensor, b: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, rope_cols: int,
@@ -164,12 +183,10 @@ def gemm_tn_accum_interleaved(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tenso
     _chk(dy, BF16, "dy"); _chk(x, BF16, "x")
     M, N = dy.shape; K = x.shape[1]
     _chk(dw, torch.float32, "dw", (N, K))
-    check(fn("snx_gemm_tn_accum_interleaved")(_p(dy), _p(x), _p(dw), M, N, K, _stream()), "snx_gemm_tn_accum_interleaved")
-
-
-class TnProblem(C.Structure):
-    _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32),
-                ("interleaved", C.c_int32), ("reserved", C.c_int32)]
+    one = (TnProblem * 1)(TnProblem(0, 0, 0, N, K, 1, 0))
+    ws, nb = _tn_ws(one, 1, M, dy.device)
+    check(fn("snx_gemm_tn_accum_interleaved")(_p(dy), _p(x), _p(dw), M, N, K, _p(ws), nb, _stream()),
+          "snx_gemm_tn_accum_interleaved")
 
 
 def gemm_tn_accum_group(problems) -> None:
@@ -186,7 +203,8 @@ def gemm_tn_accum_group(problems) -> None:
         N, K = dy.shape[1], x.shape[1]
         _chk(dw, torch.float32, "dw", (N, K))
         arr[i] = TnProblem(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, K, int(bool(inter)), 0)
-    check(fn("snx_gemm_tn_accum_group")(arr, len(problems), M, _stream()), "snx_gemm_tn_accum_group")
+    ws, nb = _tn_ws(arr, len(problems), M, problems[0][0].device)
+    check(fn("snx_gemm_tn_accum_group")(arr, len(problems), M, _p(ws), nb, _stream()), "snx_gemm_tn_accum_group")
 
 
 # ----------------------------------------------------------------------------- norms
@@ -227,8 +245,9 @@ def ln_bwd(dy: torch.Tensor, h: torch.Tensor, w: torch.Tensor, dh: torch.Tensor,
     _chk(dh, torch.float32, "dh", (T, H)); _chk(dw, torch.float32, "dw", (H,))
     if dh_bf16 is not None:
         _chk(dh_bf16, BF16, "dh_bf16", (T, H))
-    check(fn("snx_ln_bwd")(_p(dy), _p(h), _p(w), _p(dh), _p(dh_bf16), _p(dw), T, H, eps, int(overwrite), _stream()),
-          "snx_ln_bwd")
+    ws, nb = _scratch(int(fn("snx_ln_bwd_workspace_bytes")(T, H)), h.device)
+    check(fn("snx_ln_bwd")(_p(dy), _p(h), _p(w), _p(dh), _p(dh_bf16), _p(dw), T, H, eps, int(overwrite), _p(ws), nb,
+                           _stream()), "snx_ln_bwd")
 
 
 def embed_ln_bwd(dh: torch.Tensor, ids: torch.Tensor, E: torch.Tensor, w: torch.Tensor, gradE: torch.Tensor,
@@ -238,15 +257,19 @@ def embed_ln_bwd(dh: torch.Tensor, ids: torch.Tensor, E: torch.Tensor, w: torch.
     _chk(w, torch.float32, "w", (H,)); _chk(dw, torch.float32, "dw", (H,))
     if ids.numel() != T:
         raise ValueError("embed_ln_bwd: ids/dh row mismatch")
-    check(fn("snx_embed_ln_bwd")(_p(dh), _p(ids), _p(E), _p(w), _p(gradE), _p(dw), T, H, eps, pad_id, _stream()),
-          "snx_embed_ln_bwd")
+    V = E.shape[0]
+    ws, nb = _scratch(int(fn("snx_embed_ln_bwd_workspace_bytes")(T, H, V)), dh.device)
+    check(fn("snx_embed_ln_bwd")(_p(dh), _p(ids), _p(E), _p(w), _p(gradE), _p(dw), T, H, V, eps, pad_id, _p(ws), nb,
+                                 _stream()), "snx_embed_ln_bwd")
 
 
 def gelu_ln_bwd(dy: torch.Tensor, d: torch.Tensor, w: torch.Tensor, dw: torch.Tensor, eps: float) -> torch.Tensor:
     _chk(d, BF16, "d"); T, H = d.shape
     _chk(dy, BF16, "dy", (T, H)); _chk(w, torch.float32, "w", (H,)); _chk(dw, torch.float32, "dw", (H,))
     dd = torch.empty_like(d)
-    check(fn("snx_gelu_ln_bwd")(_p(dy), _p(d), _p(w), _p(dd), _p(dw), T, H, eps, _stream()), "snx_gelu_ln_bwd")
+    ws, nb = _scratch(int(fn("snx_ln_bwd_workspace_bytes")(T, H)), d.device)
+    check(fn("snx_gelu_ln_bwd")(_p(dy), _p(d), _p(w), _p(dd), _p(dw), T, H, eps, _p(ws), nb, _stream()),
+          "snx_gelu_ln_bwd")
     return dd
 
 

@@ -46,8 +46,9 @@ def test_native_data_parallel_collectives_reach_rccl(dev, nccl_world1, monkeypat
     """Same micro-steps twice: without collectives (plain world-1 early-outs) and with SNX_DIST_FORCE=1 (rank-0
     broadcast at wrap, bucketed all-reduce(AVG) during the last backward of the window, all-gather +
     reduce-scatter of the positives for cross-GPU negatives).  At world size 1 every collective is the
-    identity, so losses must be bit-equal and parameters equal up to fp32 atomic order; the bucket slices must
-    tile the flat gradient exactly once."""
+    identity and every weight gradient is reduced in a fixed order (include/snx.h "det_reduce"), so losses and
+    parameters must be BIT-equal -- through both optimizer steps --; the bucket slices must tile the flat gradient
+    exactly once."""
     from oracle import splade_oracle as O
     from snx import dist as sdist
     from src.model.losses import SPLADELossV33
@@ -87,9 +88,7 @@ def test_native_data_parallel_collectives_reach_rccl(dev, nccl_world1, monkeypat
 
     l0, s0, p0, _ = run(False)
     l1, s1, p1, m1 = run(True)
-    assert l0[:2] == l1[:2]                                  # before the first optimizer step: bit-equal
-    for a, b in zip(l0, l1):                                 # after it: fp32 atomic order -> Adam sign noise on tiny gradients
-        assert a == pytest.approx(b, rel=2e-3)
+    assert l0 == l1                                          # bit-equal, before and after the optimizer steps
     assert s0 == [[], []]                                    # nothing exchanged without a forced group
     total = m1.module.runtime.flat_grad.numel()
     for sl in s1:                                            # forced: 3 buckets tile the flat gradient exactly once
@@ -97,8 +96,7 @@ def test_native_data_parallel_collectives_reach_rccl(dev, nccl_world1, monkeypat
         assert cov[0][0] == 0 and cov[-1][1] == total and all(a[1] == b[0] for a, b in zip(cov, cov[1:])), cov
         assert 3 <= len(sl) <= 5
     for n in p0:
-        d = (p0[n] - p1[n]).abs()
-        assert float(d.max()) <= 2 * 2 * 1e-3 * 1.01 and float(d.mean()) < 0.02 * 1e-3, (n, float(d.max()), float(d.mean()))
+        assert torch.equal(p0[n], p1[n]), (n, float((p0[n] - p1[n]).abs().max()))
 
 
 @pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
@@ -107,8 +105,17 @@ def test_three_backward_micro_step_exchanges_once_after_the_last_backward(dev, n
     micro-step (the reference's call pattern, ref:train_v33_ddp.py:339-343,364).  Every backward adds into the same
     flat gradient, so the overlapped exchange must run inside the LAST of the three and every slice must be reduced
     exactly once, after the last backward call that writes it (round-2 review: it ran inside the first).  Also drives
-    the reduce-scatter + all-gather form of the bucket exchange and the reserved-CU launches of the dW kernel through
-    RCCL at world size 1; parameters after the optimizer steps must agree with the fused-pass run."""
+    the reduce-scatter + all-gather form of the bucket exchange through RCCL at world size 1.
+
+    Values.  The fused pass and the three passes are the same sum over the same token rows cut at other places (one
+    weight-gradient launch over q + p + n rows against three launches that accumulate): another fp32 summation TREE, so
+    the accumulated gradients agree to reassociation error only -- gamma_n * sum |terms| per element (n ~ 1e3 rows:
+    gamma ~ 1e-4 of the term magnitudes, measured relative L2 ~ 1e-6) -- and are compared here as a GROSS-ERROR screen,
+    relative L2 <= 1e-3 per tensor (a backward that lost or doubled a pass is off by O(1)).  Each of the two runs is
+    bit-reproducible by itself (asserted: the fused run twice).  Parameters after Adam are NOT compared tightly: an Adam
+    step is lr * sign-like, so elements whose gradient is near zero take a different step under any reassociation;
+    only the rigorous cap holds (two steps of at most lr each, per run).  Round 4 bounded the mean of that difference
+    by a number read off sample runs, which went red; the summation order itself is now pinned instead."""
     from oracle import splade_oracle as O
     from snx import dist as sdist
     from snx._lib import fn
@@ -137,17 +144,25 @@ def test_three_backward_micro_step_exchanges_once_after_the_last_backward(dev, n
         opt = T.build_optimizer(model, conf)
         sch = T.build_scheduler(opt, 0, 4)
         step = 0
+        first = None
         for i, b in enumerate(batches):
             last = (i + 1) % 2 == 0
             T.micro_step(model, loss_fn, b, step, dev, 2, last_of_window=last)
             if last:
+                if first is None:
+                    model.sync_gradients()
+                    first = model.module.runtime.flat_grad.detach().clone()     # the first window's accumulated gradient
                 T.optimizer_step(model, opt, sch, conf)
                 step += 1
         torch.cuda.synchronize()
-        assert fn("snx_get_reserved_cus")() == 0            # reset after every armed backward
+        assert fn("snx_get_reserved_cus")() == 0            # no reservation outside an armed backward
+        model.first_window_grad = first
         return {n: p.detach().clone() for n, p in model.module.named_parameters()}, gs_, model
 
-    p_fused, g_fused, _ = run(True)
+    p_fused, g_fused, m_f = run(True)
+    p_again, _, m_a = run(True)
+    assert torch.equal(m_f.first_window_grad, m_a.first_window_grad)              # bit-reproducible ...
+    assert all(torch.equal(p_fused[n], p_again[n]) for n in p_fused)              # ... through the optimizer steps
     p_three, g_three, m = run(False)
     total = m.module.runtime.flat_grad.numel()
     for gs_, nfwd in ((g_fused, 1), (g_three, 3)):
@@ -168,30 +183,35 @@ def test_three_backward_micro_step_exchanges_once_after_the_last_backward(dev, n
             cov = sorted(reds)
             assert cov[0][0] == 0 and cov[-1][1] == total and all(a[1] == b[0] for a, b in zip(cov, cov[1:])), cov
             del ev
-    # Parameters after the two Adam steps (lr 1e-3): an element moves by at most lr per step, so two runs differ by at most
-    # 2 steps x 2 lr; the MEAN difference is Adam sign noise on elements whose gradient is near zero -- the two runs sum the
-    # weight gradients in different orders (other token counts per launch, float atomics).  Measured on one MI355X over four
-    # batch seeds (profiles/r04_three_backward_noise.txt, tools/gpu_three_backward_noise.py): worst tensor 3.9e-6 .. 3.7e-5
-    # with either attention backward, and up to 6e-6 between two runs of the SAME configuration; 1e-4 = 0.1 lr bounds that
-    # distribution with margin while a slice reduced twice or not at all (what this test is for) moves whole tensors by
-    # ~lr and fails the coverage assertions above as well.
-    for n in p_fused:
-        d = (p_fused[n] - p_three[n]).abs()
-        assert float(d.max()) <= 2 * 2 * 1e-3 * 1.01 and float(d.mean()) < 0.1 * 1e-3, (n, float(d.max()), float(d.mean()))
+    off = 0
+    for i, p_ in enumerate(m.module.runtime.params):         # the flat buffer's own order
+        n = p_.numel()
+        a, b = m_f.first_window_grad[off:off + n].double(), m.first_window_grad[off:off + n].double()
+        off += n
+        assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 1e-30, (i, float((a - b).norm()), float(b.norm()))
+    for n in p_fused:                                        # two Adam steps of at most lr = 1e-3 each, per run
+        assert float((p_fused[n] - p_three[n]).abs().max()) <= 2 * 2 * 1e-3 * 1.01, n
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
-def test_overlapped_exchange_beside_the_persistent_kernels_through_rccl(dev, nccl_world1, monkeypatch, mode):
+@pytest.mark.parametrize("mode,reserved", [("allreduce", 0), ("rs_ag", 0), ("allreduce", 32)])
+def test_overlapped_exchange_beside_the_persistent_kernels_through_rccl(dev, nccl_world1, monkeypatch, mode, reserved):
     """One accumulation window of a geometry whose backward runs on the PERSISTENT kernels (256x256 weight-gradient and
     NT GEMMs, 256x192 decoder: thresholds lowered through snx_configure so that 2,176 token rows qualify), with the
     gradient exchange overlapped with the last backward -- buckets through RCCL on the exchange stream while those
-    whole-CU kernels are in flight on 256 - SNX_EXCHANGE_RESERVED_CUS = 224 CUs -- against the un-overlapped path (no
-    buckets: one all-reduce of the whole buffer after the backward, every CU to the kernels).  At world size 1 every
-    collective is the identity, so the two accumulated gradients may differ by the float-atomic order of the weight
-    gradients only (<= 2e-6 of a tensor's largest element; a bucket reduced before its last producer, a slice exchanged
-    twice or the 224-workgroup schedules dropping work would be orders of magnitude above that), and nothing may fault
-    or hang with RCCL's channel workgroups resident beside the persistent ones.  What one GPU cannot show is the
-    contention itself (RCCL at world size 1 moves no data between devices): that needs a node."""
+    whole-CU kernels are in flight -- against the un-overlapped path (no buckets: one all-reduce of the whole buffer
+    after the backward).  At world size 1 every collective is the identity and the weight gradients are reduced in a
+    fixed order (include/snx.h "det_reduce"), so with the default launch (reserved = 0: the same 256-workgroup
+    schedules in both runs) the two accumulated gradients must be BIT-equal; a bucket reduced while its last producer
+    still writes, or a unit range that skips work, cannot hide behind a tolerance.
+
+    reserved = 32 (opt-in, SNX_EXCHANGE_RESERVED_CUS): the armed backward launches 224 workgroups, and
+    csrc/gemm_tn256.hip derives its token pieces from that count -- another fp32 summation tree than the 256-workgroup
+    run's (round 4 took this for atomic-order noise and bounded it by a sampled 2e-6: red on the driver's box).  The
+    224-workgroup schedules are checked against derived bounds where the operands are known
+    (tests/test_gpu_ops.py::test_gemm_tn_256_with_reserved_cus, ..._nt256_with_reserved_cus); here only the plumbing
+    is asserted -- the reservation holds inside the armed backward only, the slices tile the buffer once -- plus a
+    gross-error screen of the gradients (relative L2 <= 1e-3 per tensor; reassociation is ~1e-6, lost work is O(1)).
+    What one GPU cannot show is the contention itself (RCCL at world size 1 moves no data between devices)."""
     import snx
     from oracle import splade_oracle as O
     from snx._lib import fn
@@ -205,7 +225,8 @@ def test_overlapped_exchange_beside_the_persistent_kernels_through_rccl(dev, ncc
     batches = [O.synth_batch(8, 16, 128, cfg, gen, k=1, ragged=False) for _ in range(2)]     # 8 x (16 + 128 + 128) rows
     monkeypatch.setenv("SNX_DIST_FORCE", "1")
     monkeypatch.setenv("SNX_GRAD_EXCHANGE", mode)
-    monkeypatch.setenv("SNX_EXCHANGE_RESERVED_CUS", "32")
+    monkeypatch.setenv("SNX_EXCHANGE_RESERVED_CUS", str(reserved))
+    before = {k: snx.config(k) for k in ("tn256_min_m", "nt256_min_m", "dec256_min_t")}
     snx.configure(tn256_min_m=1024, nt256_min_m=1024, dec256_min_t=256)
     try:
         def run(n_buckets):
@@ -221,22 +242,24 @@ def test_overlapped_exchange_beside_the_persistent_kernels_through_rccl(dev, ncc
             gs_ = model.module.runtime.grad_sync
             return model.module.runtime.flat_grad.detach().clone(), gs_, seen, model
         g_over, gs_, seen, m = run(3)
-        assert gs_ is not None and gs_.mode == mode and gs_.reserved_cus == 32
+        assert gs_ is not None and gs_.mode == mode and gs_.reserved_cus == reserved
         assert seen == [0, 0] and len(gs_.slices) == 3      # reserved only inside the armed backward, reset behind it
         cov = sorted(gs_.slices)
         assert cov[0][0] == 0 and cov[-1][1] == g_over.numel() and all(a[1] == b[0] for a, b in zip(cov, cov[1:])), cov
         g_plain, gs0, _, _ = run(0)
         assert gs0 is None
     finally:
-        snx.configure(tn256_min_m=8192, nt256_min_m=8192, dec256_min_t=2048)
+        snx.configure(**before)
     assert torch.isfinite(g_over).all() and float(g_over.abs().max()) > 0
+    if reserved == 0:
+        assert torch.equal(g_over, g_plain), float((g_over - g_plain).abs().max())
+        return
     off = 0
     for name, p_ in enumerate(m.module.runtime.params):          # the flat buffer's own order
         n = p_.numel()
         a, b = g_over[off:off + n].double(), g_plain[off:off + n].double()
         off += n
-        scale = float(b.abs().max())
-        assert float((a - b).abs().max()) <= 2e-6 * scale + 1e-12, (name, float((a - b).abs().max()), scale)
+        assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 1e-30, (name, float((a - b).norm()), float(b.norm()))
 
 
 def test_bucket_plan_covers_every_unit(dev):

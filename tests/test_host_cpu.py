@@ -42,7 +42,7 @@ def test_shape_validation_happens_on_the_host():
     one = C.c_void_p(16)
     assert fn("snx_gemm_nt_bf16")(one, one, one, 128, 128, 100, None) == -2          # K % 64 != 0
     assert fn("snx_gemm_nt_bf16")(None, one, one, 128, 128, 128, None) == -3
-    assert fn("snx_gemm_tn_accum")(one, one, one, 128, 100, 128, None) == -2          # N % 128 != 0
+    assert fn("snx_gemm_tn_accum")(one, one, one, 128, 100, 128, None, 0, None) == -2          # N % 128 != 0
     assert fn("snx_ln_fwd")(one, one, one, 4, 100, 1e-5, None) == -2                  # H % 256 != 0
     assert fn("snx_attn_fwd")(one, one, one, one, one, 64, 1, 64, 12, 32, -1, None) == -2   # head_dim != 64
     d = EncoderGeometry().desc()
@@ -60,13 +60,24 @@ def test_shape_validation_happens_on_the_host():
     # grouped weight-gradient GEMM: 1..4 problems, N and K multiples of 128, non-null operands
     from snx.ops import TnProblem
     ok = (TnProblem * 2)(TnProblem(16, 16, 16, 256, 128, 0, 0), TnProblem(16, 16, 16, 128, 128, 1, 0))
-    assert fn("snx_gemm_tn_accum_group")(ok, 0, 64, None) == -3
-    assert fn("snx_gemm_tn_accum_group")(ok, 5, 64, None) == -3
-    assert fn("snx_gemm_tn_accum_group")(None, 1, 64, None) == -3
+    assert fn("snx_gemm_tn_accum_group")(ok, 0, 64, None, 0, None) == -3
+    assert fn("snx_gemm_tn_accum_group")(ok, 5, 64, None, 0, None) == -3
+    assert fn("snx_gemm_tn_accum_group")(None, 1, 64, None, 0, None) == -3
     odd = (TnProblem * 1)(TnProblem(16, 16, 16, 100, 128, 0, 0))
-    assert fn("snx_gemm_tn_accum_group")(odd, 1, 64, None) == -2
+    assert fn("snx_gemm_tn_accum_group")(odd, 1, 64, None, 0, None) == -2
     nul = (TnProblem * 1)(TnProblem(0, 16, 16, 128, 128, 0, 0))
-    assert fn("snx_gemm_tn_accum_group")(nul, 1, 64, None) == -3
+    assert fn("snx_gemm_tn_accum_group")(nul, 1, 64, None, 0, None) == -3
+    # ordered reduction of the weight gradients: a token-split schedule without its workspace is refused on the host
+    # (no launch), and the workspace bound covers the layer group of the 149 M model at the bench's token count
+    big = (TnProblem * 1)(TnProblem(16, 16, 16, 768, 768, 0, 0))
+    need = fn("snx_gemm_tn_workspace_bytes")(big, 1, 36864)
+    assert need >= 3 * 9 * 256 * 256 * 4                                             # >= 3 token pieces x 9 tiles
+    assert fn("snx_gemm_tn_accum_group")(big, 1, 36864, None, 0, None) == -3
+    assert fn("snx_gemm_tn_accum_group")(big, 1, 36864, one, need - 1, None) == -3
+    assert fn("snx_gemm_tn_workspace_bytes")(odd, 1, 64) == 0                        # invalid shapes: 0
+    assert fn("snx_ln_bwd_workspace_bytes")(36864, 768) == 1024 * 768 * 4            # one partial dw row per block
+    assert fn("snx_embed_ln_bwd_workspace_bytes")(36864, 768, 50000) > 36864 * 768 * 4
+    assert fn("snx_ln_bwd")(one, one, one, one, None, one, 64, 768, 1e-5, 0, None, 0, None) == -3
     # backward in unit ranges: the range must lie inside [0, layers + 2) and be non-empty
     nine = [one] * 14
     L = d.layers
