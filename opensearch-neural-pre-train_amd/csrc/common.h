@@ -116,3 +116,21 @@ struct CastBatch {
   bf16_t* out_t[SNX_CAST_BATCH_MAX];
 };
 int snx_cast_both_batched(const CastBatch& b, int n, int R, int C, int interleave, hipStream_t st);
+
+// LayerNorm weight gradients, ordered reduction (elementwise.hip): a backward launch leaves one partial dw row per block in
+// its workspace; the rows of up to SNX_LN_BATCH_MAX launches are added to their dw vectors, in block order, by ONE kernel.
+// The public entry points reduce at once; the model's backward (model.hip) defers and reduces once per unit range.
+#define SNX_LN_BATCH_MAX 64
+struct LnDwBatch {
+  const float* part[SNX_LN_BATCH_MAX];
+  float* dw[SNX_LN_BATCH_MAX];
+  int nb[SNX_LN_BATCH_MAX];
+};
+int snx_ln_dw_reduce_batch(const LnDwBatch& batch, int n, int H, hipStream_t st);
+int snx_ln_bwd_x(const void* dy, const float* h, const float* w, float* dh, void* dh_bf16, float* dw, int32_t T, int32_t H,
+                 float eps, int32_t overwrite, void* ws, size_t ws_bytes, LnDwBatch* defer, int* ndefer, hipStream_t st);
+int snx_gelu_ln_bwd_x(const void* dy, const void* d, const float* w, void* dd, float* dw, int32_t T, int32_t H, float eps,
+                      void* ws, size_t ws_bytes, LnDwBatch* defer, int* ndefer, hipStream_t st);
+int snx_embed_ln_bwd_x(const float* dh, const int64_t* ids, const float* E, const float* w, float* gradE, float* dw,
+                       int32_t T, int32_t H, int32_t V, float eps, int32_t pad_id, void* ws, size_t ws_bytes,
+                       LnDwBatch* defer, int* ndefer, hipStream_t st);

@@ -391,26 +391,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// dw[c] += part[0][c] + part[1][c] + ... in block order.  One 1024-thread workgroup per 64 columns: wave g sums the
-// contiguous run of partial rows [g nb / 16, (g + 1) nb / 16) (independent 256-byte loads, all in flight at once), the 16
-// wave sums are added in wave order through LDS.
-__global__ __launch_bounds__(1024) void ln_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nb,
-                                                            int H) {
+// dw[c] += part[0][c] + part[1][c] + ... in block order, for a BATCH of LayerNorm launches (blockIdx.y): the model's
+// backward leaves every LayerNorm's partial rows in a region of its own and reduces them all in one launch per unit
+// range (45 two-kernel sequences cost 0.8 ms per micro-step; measured, profiles/r05_experiments.txt).  One 1024-thread
+// workgroup per 64 columns and launch: wave g sums the contiguous run of partial rows [g nb / 16, (g + 1) nb / 16) --
+// 16 independent 256-byte loads in flight per trip --, the 16 wave sums are added in wave order through LDS.
+__global__ __launch_bounds__(1024) void ln_dw_reduce_kernel(LnDwBatch batch, int H) {
   __shared__ float red[16][64];
+  const float* __restrict__ part = batch.part[blockIdx.y];
+  float* __restrict__ dw = batch.dw[blockIdx.y];
+  const int nb = batch.nb[blockIdx.y];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  const int c = blockIdx.x * 64 + lane;                 // H % 256 == 0: always inside
   const int b0 = (int)((long)g * nb / 16), b1 = (int)((long)(g + 1) * nb / 16);
   float s = 0.f;
-  if (c < H)
-    for (int b = b0; b < b1; ++b) s += part[(long)b * H + c];
+  int b = b0;
+  for (; b + 16 <= b1; b += 16) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = part[(long)(b + q) * H + c];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += v[q];
+  }
+  for (; b < b1; ++b) s += part[(long)b * H + c];
   red[g][lane] = s;
   __syncthreads();
-  if (g == 0 && c < H) {
+  if (g == 0) {
     float t = red[0][lane];
 #pragma unroll
     for (int q = 1; q < 16; ++q) t += red[q][lane];
     dw[c] += t;
   }
+}
+
+int snx_ln_dw_reduce_batch(const LnDwBatch& batch, int n, int H, hipStream_t st) {
+  if (n <= 0) return SNX_OK;
+  if (n > SNX_LN_BATCH_MAX) return SNX_E_ARG;
+  hipLaunchKernelGGL(ln_dw_reduce_kernel, dim3(H / 64, n), dim3(1024), 0, st, batch, H);
+  SNX_CHECK_LAUNCH();
+  return SNX_OK;
 }
 
 // ---- embedding gradient in a FIXED order ---------------------------------------------------------------------------
@@ -504,10 +523,17 @@ extern "C" size_t snx_embed_ln_bwd_workspace_bytes(int32_t T, int32_t H, int32_t
   return a + rows + ints;
 }
 
-static int ln_dw_finish(float* part, float* dw, int nb, int H, hipStream_t st) {
-  hipLaunchKernelGGL(ln_dw_reduce_kernel, dim3(cdiv(H, 64)), dim3(1024), 0, st, (const float*)part, dw, nb, H);
-  SNX_CHECK_LAUNCH();
-  return SNX_OK;
+// `defer` (the model's backward): the partial rows stay in `part` and the caller reduces them later, batched
+static int ln_dw_finish(float* part, float* dw, int nb, int H, hipStream_t st, LnDwBatch* defer = nullptr, int* ndefer = nullptr) {
+  if (defer) {
+    if (*ndefer >= SNX_LN_BATCH_MAX) return SNX_E_ARG;
+    defer->part[*ndefer] = part; defer->dw[*ndefer] = dw; defer->nb[*ndefer] = nb;
+    ++*ndefer;
+    return SNX_OK;
+  }
+  LnDwBatch one;
+  one.part[0] = part; one.dw[0] = dw; one.nb[0] = nb;
+  return snx_ln_dw_reduce_batch(one, 1, H, st);
 }
 // the workspace of a launch: nullptr with "det_reduce" = 0 (float atomics); SNX_E_ARG if it is missing or too small
 #define LN_WS(need)                                              \
@@ -517,9 +543,9 @@ static int ln_dw_finish(float* part, float* dw, int nb, int H, hipStream_t st) {
     part = (float*)ws;                                           \
   }
 
-extern "C" int snx_ln_bwd(const void* dy, const float* h, const float* w, float* dh, void* dh_bf16, float* dw,
-                          int32_t T, int32_t H, float eps, int32_t overwrite, void* ws, size_t ws_bytes,
-                          hipStream_t st) {
+int snx_ln_bwd_x(const void* dy, const float* h, const float* w, float* dh, void* dh_bf16, float* dw, int32_t T,
+                 int32_t H, float eps, int32_t overwrite, void* ws, size_t ws_bytes, LnDwBatch* defer, int* ndefer,
+                 hipStream_t st) {
   if (!dy || !h || !w || !dh || !dw || T <= 0) return SNX_E_ARG;
   if (bad_h(H)) return SNX_E_SHAPE;
   const int rpb = ln_bwd_rows_per_block(T);
@@ -535,12 +561,22 @@ extern "C" int snx_ln_bwd(const void* dy, const float* h, const float* w, float*
                                       (bf16_t*)dh_bf16, nullptr, nullptr, dw, part, T, H, eps, rpb, -1));
   }
   SNX_CHECK_LAUNCH();
-  return part ? ln_dw_finish(part, dw, nb, H, st) : SNX_OK;
+  return part ? ln_dw_finish(part, dw, nb, H, st, defer, ndefer) : SNX_OK;
+}
+extern "C" int snx_ln_bwd(const void* dy, const float* h, const float* w, float* dh, void* dh_bf16, float* dw,
+                          int32_t T, int32_t H, float eps, int32_t overwrite, void* ws, size_t ws_bytes,
+                          hipStream_t st) {
+  return snx_ln_bwd_x(dy, h, w, dh, dh_bf16, dw, T, H, eps, overwrite, ws, ws_bytes, nullptr, nullptr, st);
 }
 
 extern "C" int snx_embed_ln_bwd(const float* dh, const int64_t* ids, const float* E, const float* w, float* gradE,
                                 float* dw, int32_t T, int32_t H, int32_t V, float eps, int32_t pad_id, void* ws,
                                 size_t ws_bytes, hipStream_t st) {
+  return snx_embed_ln_bwd_x(dh, ids, E, w, gradE, dw, T, H, V, eps, pad_id, ws, ws_bytes, nullptr, nullptr, st);
+}
+int snx_embed_ln_bwd_x(const float* dh, const int64_t* ids, const float* E, const float* w, float* gradE, float* dw,
+                       int32_t T, int32_t H, int32_t V, float eps, int32_t pad_id, void* ws, size_t ws_bytes,
+                       LnDwBatch* defer, int* ndefer, hipStream_t st) {
   if (!dh || !ids || !E || !w || !gradE || !dw || T <= 0 || V <= 0) return SNX_E_ARG;
   if (bad_h(H)) return SNX_E_SHAPE;
   const int rpb = ln_bwd_rows_per_block(T);
@@ -570,11 +606,15 @@ extern "C" int snx_embed_ln_bwd(const float* dh, const int64_t* ids, const float
   DISPATCH_NV(H, hipLaunchKernelGGL((embed_scatter_kernel<NV>), dim3(cdiv(T, 4)), dim3(256), 0, st, (const float*)dxrows,
                                     ids, (const int*)off, (const int*)sorted, gradE, T, H, V, pad_id));
   SNX_CHECK_LAUNCH();
-  return ln_dw_finish(part, dw, nb, H, st);
+  return ln_dw_finish(part, dw, nb, H, st, defer, ndefer);
 }
 
 extern "C" int snx_gelu_ln_bwd(const void* dy, const void* d, const float* w, void* dd, float* dw, int32_t T,
                                int32_t H, float eps, void* ws, size_t ws_bytes, hipStream_t st) {
+  return snx_gelu_ln_bwd_x(dy, d, w, dd, dw, T, H, eps, ws, ws_bytes, nullptr, nullptr, st);
+}
+int snx_gelu_ln_bwd_x(const void* dy, const void* d, const float* w, void* dd, float* dw, int32_t T, int32_t H,
+                      float eps, void* ws, size_t ws_bytes, LnDwBatch* defer, int* ndefer, hipStream_t st) {
   if (!dy || !d || !w || !dd || !dw || T <= 0) return SNX_E_ARG;
   if (bad_h(H)) return SNX_E_SHAPE;
   const int rpb = ln_bwd_rows_per_block(T);
@@ -584,7 +624,7 @@ extern "C" int snx_gelu_ln_bwd(const void* dy, const void* d, const float* w, vo
                                     (const bf16_t*)dy, nullptr, nullptr, nullptr, nullptr, (const bf16_t*)d, w,
                                     nullptr, nullptr, nullptr, (bf16_t*)dd, dw, part, T, H, eps, rpb, -1));
   SNX_CHECK_LAUNCH();
-  return part ? ln_dw_finish(part, dw, nb, H, st) : SNX_OK;
+  return part ? ln_dw_finish(part, dw, nb, H, st, defer, ndefer) : SNX_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -128,7 +128,9 @@ struct BwdPlan {
   // workspaces of the ORDERED weight-gradient reductions ("det_reduce"): partial slabs of the layer's grouped dW launch
   // (side stream), of the head's dW launch (launch stream: may overlap the side stream's), partial dw rows of the
   // LayerNorm backward launches + the embedding gradient's token lists and dx rows (launch stream, one at a time)
-  size_t tnws_side, tnws_side_bytes, tnws_main, tnws_main_bytes, lnws, lnws_bytes;
+  size_t tnws_side, tnws_side_bytes, tnws_main, tnws_main_bytes;
+  size_t lnws, ln_slot, lnws_emb, lnws_emb_bytes;   // one slot of partial dw rows per LayerNorm (reduced in one batched launch per
+                                                    // unit range), the embedding's workspace behind them
   size_t total;
 };
 
@@ -149,11 +151,13 @@ void plan_bwd(const snx_model_desc* d, long T, long nseq, long max_seqlen, BwdPl
                                      {nullptr, nullptr, nullptr, Hh, Ii, 0, 0}, {nullptr, nullptr, nullptr, Hh, Hh, 0, 0}};
     p.tnws_side_bytes = snx_gemm_tn_workspace_bytes(layer, 4, (int32_t)T);
     p.tnws_main_bytes = snx_gemm_tn_workspace_bytes(layer + 3, 1, (int32_t)T);
-    p.lnws_bytes = snx_embed_ln_bwd_workspace_bytes((int32_t)T, Hh, d->vocab);
+    p.ln_slot = al(snx_ln_bwd_workspace_bytes((int32_t)T, Hh));
+    p.lnws_emb_bytes = snx_embed_ln_bwd_workspace_bytes((int32_t)T, Hh, d->vocab);
   }
   p.tnws_side = take(p.tnws_side_bytes);
   p.tnws_main = take(p.tnws_main_bytes);
-  p.lnws = take(p.lnws_bytes);
+  p.lnws = take(p.ln_slot * (2 * (size_t)d->layers + 2));
+  p.lnws_emb = take(p.lnws_emb_bytes);
   p.total = off;
 }
 
@@ -449,7 +453,11 @@ extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* con
   float* dh = (float*)(sc + b.dh);
   char* Bb = sc + b.b;
   const long n4 = (long)T * H / 4;
-#define LNWS sc + b.lnws, b.lnws_bytes
+  // LayerNorm weight gradients: every launch leaves its partial rows in a slot of its own (slot 0 head norm, 1 final
+  // norm, 2 + 2l / 3 + 2l the layer's mlp / attention norm); ONE batched kernel adds them to dw at the end of this call
+  LnDwBatch lnb;
+  int nlnb = 0;
+#define LNWS(slot) sc + b.lnws + (size_t)(slot) * b.ln_slot, b.ln_slot, &lnb, &nlnb
 
   // The weight-gradient GEMMs go to the side stream unless the per-class profiler is timing kernels one by one:
   // one GROUPED launch per layer (its four Linears), issued after the layer's dX chain.
@@ -482,12 +490,12 @@ extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* con
     { PROF(PC_SPLADE_BWD, 2.0 * 2.0 * nseq * V * H);
       RC(snx_splade_bwd(g_sparse, (const uint32_t*)(sv + s.keys), sv + s.hd, wc + c.emb, cu_seqlens, A, G(p.tok_emb()),
                         G(p.dec_bias()), sc + b.splade, T, nseq, max_seqlen, V, H, st)); }
-    { PROF(PC_LN_BWD, TH * 6); RC(snx_gelu_ln_bwd(A, sv + s.dd, F(p.head_norm()), Bb, G(p.head_norm()), T, H, d->ln_eps, LNWS, st)); }
+    { PROF(PC_LN_BWD, TH * 6); RC(snx_gelu_ln_bwd_x(A, sv + s.dd, F(p.head_norm()), Bb, G(p.head_norm()), T, H, d->ln_eps, LNWS(0), st)); }
     { PROF(PC_GEMM_TN, 2.0 * TH * H);
       RC(snx_gemm_tn_accum(Bb, sv + s.xf, G(p.head_dense()), T, H, H, sc + b.tnws_main, b.tnws_main_bytes, st)); }
     { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(Bb, wc + c.dense_t, A, T, H, H, st)); }
     // every LayerNorm backward also emits bf16(dh): the gradient of the next bf16 branch output
-    { PROF(PC_LN_BWD, TH * 12); RC(snx_ln_bwd(A, hbuf(2 * L), F(p.final_norm()), dh, A, G(p.final_norm()), T, H, d->ln_eps, 1, LNWS, st)); }
+    { PROF(PC_LN_BWD, TH * 12); RC(snx_ln_bwd_x(A, hbuf(2 * L), F(p.final_norm()), dh, A, G(p.final_norm()), T, H, d->ln_eps, 1, LNWS(1), st)); }
   }
 
   const int l_hi = L - 1 - (unit_begin > 1 ? unit_begin - 1 : 0);
@@ -503,7 +511,7 @@ extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* con
     { PROF(PC_GEMM_NT, 2.0 * TH * I);             // dy = dh Wo, GeGLU backward fused -> du [T,2I] (interleaved)
       RC(snx_gemm_nt_geglu_bwd(P, wc + c.wom_t[l], sv + s.u[l], Du, T, I, H, st)); }
     { PROF(PC_GEMM_NT, 2.0 * TH * 2 * I); RC(snx_gemm_nt_bf16(Du, wc + c.wi_t[l], Q, T, H, 2 * I, st)); }   // dx [T,H]
-    { PROF(PC_LN_BWD, TH * 16); RC(snx_ln_bwd(Q, hbuf(2 * l + 1), F(p.mlp_norm(l)), dh, Q, G(p.mlp_norm(l)), T, H, d->ln_eps, 0, LNWS, st)); }
+    { PROF(PC_LN_BWD, TH * 16); RC(snx_ln_bwd_x(Q, hbuf(2 * l + 1), F(p.mlp_norm(l)), dh, Q, G(p.mlp_norm(l)), T, H, d->ln_eps, 0, LNWS(2 + 2 * l), st)); }
     // ---- attention:  h[2l+1] = h[2l] + Wo( attn( rope( Wqkv( LN(h[2l]) ) ) ) )
     { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(Q, wc + c.wo_t[l], Bb, T, H, H, st)); }    // d(attn out)
     { PROF(PC_ATTN_BWD, 10.0 * H * pairs);
@@ -524,9 +532,13 @@ extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* con
       RC(snx_gemm_tn_accum_group(pr, 4, T, sc + b.tnws_side, b.tnws_side_bytes, ss));
     }
     RC(mark(g_side.done[k]));
+    if (nlnb > SNX_LN_BATCH_MAX - 4) {                  // deep models: reduce what is pending before the batch is full
+      RC(snx_ln_dw_reduce_batch(lnb, nlnb, H, st));
+      nlnb = 0;
+    }
     if (l > 0) {
       PROF(PC_LN_BWD, TH * 16);
-      RC(snx_ln_bwd(Pn, hbuf(2 * l), F(p.attn_norm(l)), dh, Pn, G(p.attn_norm(l)), T, H, d->ln_eps, 0, LNWS, st));
+      RC(snx_ln_bwd_x(Pn, hbuf(2 * l), F(p.attn_norm(l)), dh, Pn, G(p.attn_norm(l)), T, H, d->ln_eps, 0, LNWS(3 + 2 * l), st));
     } else {
       PROF(PC_CAST, TH * 10);
       hipLaunchKernelGGL(add_bf16_into_f32_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, dh, (const bf16_t*)Pn, n4);
@@ -537,9 +549,11 @@ extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* con
     RC(join(g_side.done[0]));                      // the side stream is in order: its last two marks cover all of it
     RC(join(g_side.done[1]));
     { PROF(PC_EMBED, TH * 12);
-      RC(snx_embed_ln_bwd(dh, ids, F(p.tok_emb()), F(p.emb_norm()), G(p.tok_emb()), G(p.emb_norm()), T, H, V, d->ln_eps,
-                          d->pad_id, LNWS, st)); }
+      RC(snx_embed_ln_bwd_x(dh, ids, F(p.tok_emb()), F(p.emb_norm()), G(p.tok_emb()), G(p.emb_norm()), T, H, V, d->ln_eps,
+                            d->pad_id, sc + b.lnws_emb, b.lnws_emb_bytes, &lnb, &nlnb, st)); }
   }
+  if (nlnb > 0) { PROF(PC_LN_BWD, 0); RC(snx_ln_dw_reduce_batch(lnb, nlnb, H, st)); }
+#undef LNWS
   if (notify) {
     // `notify` learns that every gradient written by units [unit_begin, unit_end) is complete: it waits for
     // this point of the launch stream and of the weight-gradient side stream (the caller's stream does not)
