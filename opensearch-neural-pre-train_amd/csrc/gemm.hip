@@ -256,6 +256,11 @@ static int launch_nt(const void* A, const void* B, int M, int N, int K, const Ep
   if ((EPI == EPI_ROPE || EPI == EPI_GEGLU_FWD) && (N % 64) != 0) return SNX_E_SHAPE;
   if (EPI == EPI_GEGLU_BWD && (N % 32) != 0) return SNX_E_SHAPE;
   if (!A || !B) return SNX_E_ARG;
+  if (EPI == EPI_GEGLU_BWD) {
+    // the pipelined 128x128 form (gemm_nt_pipe.hip): the epilogue of a tile inside the K loop of the next one
+    const int rc = snx_launch_nt_pipe_geglu_bwd(A, B, M, N, K, e, st);
+    if (rc != SNX_E_SHAPE) return rc;
+  }
   {
     // many rows: the 256x256 persistent form (gemm_nt256.hip); SNX_E_SHAPE = not taken (small M, odd N, epilogue
     // not built there yet)

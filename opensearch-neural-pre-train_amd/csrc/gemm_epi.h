@@ -55,3 +55,5 @@ __device__ __forceinline__ bf16x8 stg32_get(const char* w, int row, int chunk) {
 // 256x256 persistent kernel (gemm_nt256.hip).  SNX_OK, SNX_E_SHAPE when it does not take the shape (the caller
 // falls back to the 128x128 kernel), or a HIP error code.
 int snx_launch_nt256(int epi, const void* A, const void* B, int M, int N, int K, const EpiArgs& e, hipStream_t st);
+// pipelined 128x128 form of the GeGLU-backward GEMM (gemm_nt_pipe.hip): same contract
+int snx_launch_nt_pipe_geglu_bwd(const void* A, const void* B, int M, int N, int K, const EpiArgs& e, hipStream_t st);

@@ -34,7 +34,16 @@ GUARDED: Dict[str, Tuple[str, ...]] = {
     "gemm_nt256.hip": ("gemm_nt256_kernel",),
 }
 
+# Kernels whose epilogue operands are loaded by volatile-asm global loads with the wait left to the SCHEDULE (a counted
+# s_waitcnt vmcnt two K-steps later): nothing may touch a load's destination before a vmcnt wait that retires it.
+VM_GUARDED: Dict[str, Tuple[str, ...]] = {
+    "gemm_nt_pipe.hip": ("gemm_nt_geglu_bwd_pipe_kernel",),
+}
+
 _REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
+_VMCNT = re.compile(r"vmcnt\((\d+)\)")
+_VM_OPS = ("global_load", "global_store", "global_atomic", "flat_load", "flat_store", "flat_atomic", "scratch_load",
+           "scratch_store", "buffer_load", "buffer_store", "buffer_atomic")
 _LGKM = re.compile(r"lgkmcnt\((\d+)\)")
 
 
@@ -120,6 +129,54 @@ def _scan(lines: List[str], start: int, stop: int, pending: List[Tuple[set, str]
             pending.append((_regs(ops.split(",")[0]), ins))
 
 
+def _scan_vm(lines: List[str], start: int, stop: int, pending: List[Tuple[set, str, int]], issued: int, bad: List[str],
+             labels: Dict[str, int], follow: bool) -> None:
+    """The vm-counter twin of _scan: vector-memory instructions retire in issue order, so `s_waitcnt vmcnt(N)` retires
+    every load that is not among the N newest vm instructions (loads, stores, LDS-DMA, scratch alike)."""
+    i = start
+    while i < stop:
+        ins = lines[i]
+        i += 1
+        if ins.endswith(":"):
+            continue
+        op = ins.split()[0]
+        if op == "s_waitcnt":
+            m = _VMCNT.search(ins)
+            if m is None and re.search(r"s_waitcnt\s+(0x[0-9a-f]+|\d+)\s*$", ins):
+                n = 0                        # an immediate without names: every counter
+            elif m is None:
+                continue
+            else:
+                n = int(m.group(1))
+            pending = [p for p in pending if issued - 1 - p[2] < n]
+            continue
+        if follow and pending and (op.startswith("s_cbranch") or op == "s_branch"):
+            tgt = labels.get(ins.split()[-1])
+            if tgt is not None and tgt < i:
+                _scan_vm(lines, tgt, i - 1, list(pending), issued, bad, labels, False)
+            continue
+        touched = _regs(ins.split(None, 1)[1]) if " " in ins else set()
+        if pending and touched:
+            for dst, rd, _ in pending:
+                if dst & touched:
+                    bad.append(f"{ins}   <-   {rd}")
+                    break
+        if op.startswith(_VM_OPS):
+            if op.startswith("global_load") and "_lds_" not in op:
+                pending.append((_regs(ins.split(None, 1)[1].split(",")[0]), ins, issued))
+            issued += 1
+
+
+def scan_kernel_vm(lines: Iterable[str]) -> List[str]:
+    """Violations: an instruction touches the destination of a global load before a vmcnt wait that retires the load.
+    hipcc places such waits for the loads it can see; the scan exists for loads issued through volatile asm."""
+    lines = list(lines)
+    labels = {ln[:-1]: i for i, ln in enumerate(lines) if ln.endswith(":")}
+    bad: List[str] = []
+    _scan_vm(lines, 0, len(lines), [], 0, bad, labels, True)
+    return list(dict.fromkeys(bad))
+
+
 def scan_kernel(lines: Iterable[str]) -> List[str]:
     """Violations: 'instruction <- ds_read' pairs where a pending LDS-read destination is touched too early.  The scan is
     linear in text order (forward branches: the fall-through path and the taken path both lie ahead in the text, so a
@@ -132,9 +189,10 @@ def scan_kernel(lines: Iterable[str]) -> List[str]:
     return list(dict.fromkeys(bad))
 
 
-def check_asm(asm: str, names: Iterable[str], where: str = "", allow_scratch: bool = False) -> Dict[str, dict]:
+def check_asm(asm: str, names: Iterable[str], where: str = "", allow_scratch: bool = False, vm: bool = False) -> Dict[str, dict]:
     """Raises AsmGuardError on a violation; returns {kernel: {'scratch':, 'reads':}} otherwise.  allow_scratch:
-    diagnostics builds (-DSNX_GEMM_TRACE keeps a time stamp in scratch) are held to the scan alone."""
+    diagnostics builds (-DSNX_GEMM_TRACE keeps a time stamp in scratch) are held to the scan alone.  vm: the
+    global-load / vmcnt rule (VM_GUARDED) instead of the LDS-read / lgkmcnt one."""
     ks = kernels_of(asm)
     report = {}
     for want in names:
@@ -147,7 +205,11 @@ def check_asm(asm: str, names: Iterable[str], where: str = "", allow_scratch: bo
             if scratch != 0 and not allow_scratch:
                 raise AsmGuardError(f"{where}: {k} uses {scratch} bytes of scratch per lane (spills to memory): the "
                                     "asm LDS reads are only safe in a kernel whose registers all stay in the register file")
-            bad = scan_kernel(ks[k])
+            bad = scan_kernel_vm(ks[k]) if vm else scan_kernel(ks[k])
+            if bad and vm:
+                raise AsmGuardError(f"{where}: {k}: {len(bad)} instruction(s) touch the destination of a global load before "
+                                    "a s_waitcnt vmcnt that retires it (a copy/spill the compiler placed behind an asm "
+                                    "global_load):\n  " + "\n  ".join(bad[:8]))
             if bad:
                 raise AsmGuardError(f"{where}: {k}: {len(bad)} instruction(s) touch the destination of an LDS read before "
                                     "the s_waitcnt lgkmcnt that retires it (a spill/copy the compiler placed behind an asm "
@@ -172,12 +234,23 @@ def compile_asm(src: str, extra_flags: Iterable[str] = ()) -> str:
 def check_file(basename: str, extra_flags: Iterable[str] = (), allow_scratch: bool = False) -> Dict[str, dict]:
     src = os.path.join(CSRC, basename)
     flags = list(extra_flags)
-    return check_asm(compile_asm(src, flags), GUARDED[basename], f"{basename} {' '.join(flags)}".strip(), allow_scratch)
+    where = f"{basename} {' '.join(flags)}".strip()
+    asm = compile_asm(src, flags)
+    rep = {}
+    if basename in GUARDED:
+        rep.update(check_asm(asm, GUARDED[basename], where, allow_scratch))
+    if basename in VM_GUARDED:
+        rep.update(check_asm(asm, VM_GUARDED[basename], where, allow_scratch, vm=True))
+    return rep
+
+
+def all_guarded() -> List[str]:
+    return sorted(set(GUARDED) | set(VM_GUARDED))
 
 
 def check_all(extra_flags: Iterable[str] = (), allow_scratch: bool = False) -> Dict[str, dict]:
     rep = {}
-    for b in GUARDED:
+    for b in all_guarded():
         if os.path.exists(os.path.join(CSRC, b)):
             rep.update(check_file(b, extra_flags, allow_scratch))
     return rep

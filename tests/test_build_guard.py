@@ -48,6 +48,31 @@ def test_scanner_on_hand_written_streams():
     assert A.scan_kernel(addr) == []
 
 
+def test_vm_rule_on_hand_written_streams():
+    """The global-load / vmcnt twin of the scanner (gemm_nt_pipe.hip loads its epilogue operands through volatile asm and
+    leaves the wait to a counted s_waitcnt vmcnt two K-steps later): vector-memory instructions retire in issue order, so
+    vmcnt(N) retires a load unless it is among the N newest vm instructions -- loads, stores and LDS-DMA alike."""
+    ok = ["global_load_dwordx4 v[24:27], v[44:45], off", "global_load_lds_dwordx4 v[4:5], off",
+          "global_load_lds_dwordx4 v[4:5], off", "s_waitcnt vmcnt(2)", "v_lshlrev_b32_e32 v46, 16, v24"]
+    assert A.scan_kernel_vm(ok) == []
+    early = ok[:3] + ["s_waitcnt vmcnt(3)", "v_lshlrev_b32_e32 v46, 16, v24"]
+    assert len(A.scan_kernel_vm(early)) == 1
+    # a store behind the load counts like any vm instruction; an lgkmcnt wait retires nothing here
+    st = ["global_load_dwordx4 v[24:27], v[44:45], off", "global_store_dwordx4 v[2:3], v[8:11], off",
+          "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v1, v25"]
+    assert len(A.scan_kernel_vm(st)) == 1
+    assert A.scan_kernel_vm(st[:2] + ["s_waitcnt vmcnt(1)", "v_mov_b32_e32 v1, v25"]) == []
+    # spilling the destination before the wait is the failure the rule exists for; the address registers are free at once
+    sp = ["global_load_dwordx4 v[24:27], v[44:45], off", "scratch_store_dwordx4 off, v[24:27], off", "s_waitcnt vmcnt(0)"]
+    assert len(A.scan_kernel_vm(sp)) == 1
+    assert A.scan_kernel_vm(["global_load_dwordx4 v[24:27], v[44:45], off", "v_add_u32_e32 v44, 64, v44",
+                             "s_waitcnt vmcnt(0)"]) == []
+    # a load at the bottom of a loop whose wait sits at the loop top: a use on the back-edge path is found
+    loop = [".LBB0_1:", "v_mov_b32_e32 v1, v24", "s_waitcnt vmcnt(0)", "global_load_dwordx4 v[24:27], v[44:45], off",
+            "s_cbranch_scc1 .LBB0_1"]
+    assert len(A.scan_kernel_vm(loop)) == 1
+
+
 def test_kernel_splitter_and_scratch_rule():
     asm = """
 \t.text

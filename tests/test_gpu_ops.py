@@ -777,6 +777,44 @@ def test_fused_geglu_epilogues(dev, T, H, I):
     _ulp_close(dx, dx_ref, "dx interleaved", frac_exact=0.95)
 
 
+@pytest.mark.parametrize("M,N", [(36864, 1152), (4096, 128), (4224, 384), (12800, 1152)])
+def test_geglu_bwd_pipelined_kernel_equals_the_128_kernel_bit_for_bit(dev, M, N):
+    """gemm_nt_pipe.hip: the GeGLU-backward GEMM with a tile's epilogue cut into pieces that ride in the K loop of the
+    workgroup's next tile (asm loads of the saved u covered by counted waits, results parked in LDS + registers).  Same
+    products in the same order, same epilogue arithmetic: BIT-identical to the 128x128 kernel of gemm.hip (`nt_pipe` =
+    0) -- at the bench shape (5.06 tiles per workgroup: uneven tile counts, the drain of the last tile), with fewer
+    tiles than workgroups, with one tile per workgroup exactly (the first-tile path only), and three times in a row
+    (a wait that is one instruction short shows up as a run-to-run difference)."""
+    import snx
+    ops = _ops()
+    K = 768
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dev).to(BF16)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(BF16)
+    u = torch.randn(M, 2 * N, generator=g).to(dev).to(BF16)
+    assert snx.config("nt_pipe") == 1
+    outs = [ops.gemm_nt_geglu_bwd(a, b, u) for _ in range(3)]
+    snx.configure(nt_pipe=0)
+    try:
+        ref = ops.gemm_nt_geglu_bwd(a, b, u)
+    finally:
+        snx.configure(nt_pipe=1)
+    for o in outs:
+        assert torch.equal(o, ref), float((o.float() - ref.float()).abs().max())
+    # and against plain math on a slice: dy = bf16(a b^T); da = bf16(bf16(dy g) gelu'(a)), dg = bf16(dy bf16(gelu(a)))
+    rows = slice(M - 256, M)
+    dy = (a[rows].float() @ b.float().t()).to(BF16).float()
+    uu = u[rows].float().view(256, N // 32, 2, 32)
+    ua, ug = uu[:, :, 0].reshape(256, N), uu[:, :, 1].reshape(256, N)
+    phi = 0.5 * (1 + torch.erf(ua.double() / math.sqrt(2))).float()
+    gelu = (ua * phi).to(BF16).float()
+    dgelu = phi + ua * torch.exp(-0.5 * ua * ua) * 0.3989422804014327
+    da = ((dy * ug).to(BF16).float() * dgelu).to(BF16)
+    dg = (dy * gelu).to(BF16)
+    want = torch.stack([da.view(256, N // 32, 32), dg.view(256, N // 32, 32)], 2).reshape(256, 2 * N)
+    _ulp_close(ref[rows], want, "geglu_bwd vs torch", frac_exact=0.9)
+
+
 def test_attention_bwd_fused_inverse_rope(dev):
     ops = _ops()
     B, S, heads = 2, 130, 2

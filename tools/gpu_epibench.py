@@ -53,3 +53,7 @@ report("geglu_fwd N=2304 K=768", timeit(lambda: ops.gemm_nt_geglu_fwd(x, wi)), 2
 u = rnd(M, 2 * I); wot = rnd(I, H, scale=0.05)
 report("store  N=1152 K=768", timeit(lambda: ops.gemm_nt(x, wot)), 2.0 * M * I * H)
 report("geglu_bwd N=1152 K=768", timeit(lambda: ops.gemm_nt_geglu_bwd(x, wot, u)), 2.0 * M * I * H)
+import snx
+snx.configure(nt_pipe=0)
+report("geglu_bwd (128x128 kernel)", timeit(lambda: ops.gemm_nt_geglu_bwd(x, wot, u)), 2.0 * M * I * H)
+snx.configure(nt_pipe=1)
