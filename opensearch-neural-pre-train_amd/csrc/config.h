@@ -22,7 +22,9 @@ struct SnxConfig {
   int wcache_per_tensor = 0;  // bf16 weight cache refreshed one launch per tensor
   int resid_in_ln = 1;        // forward: Wo GEMMs store bf16, the residual add happens inside the following LayerNorm
                               // (0: in the GEMM's fp32 epilogue; same bits, 0.17 ms per micro-step slower)
-  int nt_pipe = 1;            // GeGLU-backward GEMM on the pipelined 128x128 kernel (gemm_nt_pipe.hip; 0: gemm.hip's kernel)
+  int nt_pipe = 2;            // GeGLU-backward GEMM on the helper-wave kernel (gemm_nt_pipe.hip): 2 = plain du stores (default:
+                              // the next two GEMMs read du), 1 = non-temporal du stores (faster alone, equal in the step),
+                              // 0 = gemm.hip's 128x128 kernel
   int nt_pipe_min_m = 4096;
   int det_reduce = 1;         // weight gradients reduced in a FIXED order (partial slabs in the caller's workspace + an
                               // ordered reduction; bit-reproducible).  0: float atomics in arrival order (rounds 1-4; A/B)

@@ -34,8 +34,10 @@ GUARDED: Dict[str, Tuple[str, ...]] = {
     "gemm_nt256.hip": ("gemm_nt256_kernel",),
 }
 
-# Kernels whose epilogue operands are loaded by volatile-asm global loads with the wait left to the SCHEDULE (a counted
-# s_waitcnt vmcnt two K-steps later): nothing may touch a load's destination before a vmcnt wait that retires it.
+# Kernels held to the global-load / vmcnt rule: nothing may touch a load's destination before a vmcnt wait that retires it.
+# Written for the first form of gemm_nt_pipe.hip (epilogue operands loaded by volatile-asm global loads, the wait left to
+# a counted s_waitcnt vmcnt two K-steps later: the rule found a missing wait in its drain code at the first build); the
+# helper-wave form loads through plain C++ again and passes trivially, with zero scratch.
 VM_GUARDED: Dict[str, Tuple[str, ...]] = {
     "gemm_nt_pipe.hip": ("gemm_nt_geglu_bwd_pipe_kernel",),
 }

@@ -779,12 +779,13 @@ def test_fused_geglu_epilogues(dev, T, H, I):
 
 @pytest.mark.parametrize("M,N", [(36864, 1152), (4096, 128), (4224, 384), (12800, 1152)])
 def test_geglu_bwd_pipelined_kernel_equals_the_128_kernel_bit_for_bit(dev, M, N):
-    """gemm_nt_pipe.hip: the GeGLU-backward GEMM with a tile's epilogue cut into pieces that ride in the K loop of the
-    workgroup's next tile (asm loads of the saved u covered by counted waits, results parked in LDS + registers).  Same
-    products in the same order, same epilogue arithmetic: BIT-identical to the 128x128 kernel of gemm.hip (`nt_pipe` =
-    0) -- at the bench shape (5.06 tiles per workgroup: uneven tile counts, the drain of the last tile), with fewer
-    tiles than workgroups, with one tile per workgroup exactly (the first-tile path only), and three times in a row
-    (a wait that is one instruction short shows up as a run-to-run difference)."""
+    """gemm_nt_pipe.hip: the GeGLU-backward GEMM in persistent workgroups of four MFMA waves + two helper waves -- a
+    finished tile is handed over through LDS (bf16 image + parked registers, ordered by the K loop's own barriers) and
+    its epilogue (saved u in, GELU / GELU' arithmetic, du out) runs on the helpers while the MFMA waves multiply the
+    next tile.  Same products in the same order, same epilogue arithmetic: BIT-identical to the 128x128 kernel of
+    gemm.hip (`nt_pipe` = 0) -- at the bench shape (5.06 tiles per workgroup: uneven tile counts, first / middle /
+    drain periods), with fewer tiles than workgroups, with one tile per workgroup exactly (first + drain only), and
+    three times in a row (a hand-over that races shows up as a run-to-run difference)."""
     import snx
     ops = _ops()
     K = 768
@@ -792,18 +793,20 @@ def test_geglu_bwd_pipelined_kernel_equals_the_128_kernel_bit_for_bit(dev, M, N)
     a = (torch.randn(M, K, generator=g) * 0.5).to(dev).to(BF16)
     b = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(BF16)
     u = torch.randn(M, 2 * N, generator=g).to(dev).to(BF16)
-    assert snx.config("nt_pipe") == 1
+    assert snx.config("nt_pipe") == 2
     outs = [ops.gemm_nt_geglu_bwd(a, b, u) for _ in range(3)]
-    snx.configure(nt_pipe=0)
     try:
+        snx.configure(nt_pipe=1)                             # the same kernel with non-temporal du stores
+        outs.append(ops.gemm_nt_geglu_bwd(a, b, u))
+        snx.configure(nt_pipe=0)
         ref = ops.gemm_nt_geglu_bwd(a, b, u)
     finally:
-        snx.configure(nt_pipe=1)
+        snx.configure(nt_pipe=2)
     for o in outs:
         assert torch.equal(o, ref), float((o.float() - ref.float()).abs().max())
     # and against plain math on a slice: dy = bf16(a b^T); da = bf16(bf16(dy g) gelu'(a)), dg = bf16(dy bf16(gelu(a)))
     rows = slice(M - 256, M)
-    dy = (a[rows].float() @ b.float().t()).to(BF16).float()
+    dy = ops.gemm_nt(a[rows].contiguous(), b).float()        # the kernels' own bf16 dy (same k order: same bits)
     uu = u[rows].float().view(256, N // 32, 2, 32)
     ua, ug = uu[:, :, 0].reshape(256, N), uu[:, :, 1].reshape(256, N)
     phi = 0.5 * (1 + torch.erf(ua.double() / math.sqrt(2))).float()

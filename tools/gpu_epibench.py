@@ -56,4 +56,4 @@ report("geglu_bwd N=1152 K=768", timeit(lambda: ops.gemm_nt_geglu_bwd(x, wot, u)
 import snx
 snx.configure(nt_pipe=0)
 report("geglu_bwd (128x128 kernel)", timeit(lambda: ops.gemm_nt_geglu_bwd(x, wot, u)), 2.0 * M * I * H)
-snx.configure(nt_pipe=1)
+snx.configure(nt_pipe=2)

@@ -33,6 +33,9 @@ u = torch.randn(M, 2 * I, device=dev).to(BF16)
 tag = os.path.basename(os.environ.get("SNX_LIB", "libsnx.so"))
 us = timeit(lambda: ops.gemm_nt_geglu_bwd(x, wot, u))
 print(f"{tag:22s} pipelined   {us:8.1f} us  {2.0 * M * I * H / us / 1e6:7.1f} TFLOP/s", flush=True)
+snx.configure(nt_pipe=1)
+us = timeit(lambda: ops.gemm_nt_geglu_bwd(x, wot, u))
+print(f"{tag:22s} nt stores   {us:8.1f} us  {2.0 * M * I * H / us / 1e6:7.1f} TFLOP/s", flush=True)
 snx.configure(nt_pipe=0)
 us = timeit(lambda: ops.gemm_nt_geglu_bwd(x, wot, u))
 print(f"{tag:22s} 128x128     {us:8.1f} us  {2.0 * M * I * H / us / 1e6:7.1f} TFLOP/s", flush=True)
