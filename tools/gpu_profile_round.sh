@@ -1,13 +1,14 @@
 #!/bin/bash
 # Round profile set (run on the GPU box through gpurun; summaries are copied into profiles/ afterwards):
 #   bench JSON (config 2 and config 5), rocprofv3 kernel stats of the same command, PMC fabric traffic (two passes).
-R=${1:-r03}
+R=${1:-r05}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/prof_$R
 rm -rf $O; mkdir -p $O
 echo "[prof] kernel stats"; SNX_BWD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-profile --no-item-sync-leg > $O/stats.log 2>&1 || exit 1
 echo "[prof] kernel stats overlap"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_overlap -o b -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-profile --no-item-sync-leg > $O/stats_overlap.log 2>&1 || exit 1
+echo "[prof] kernel stats cfg5"; SNX_BWD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg5 -o b -- python3 bench.py --d-len 512 --negatives 4 --margin-mse 0.5 --steps 8 --warmup 4 --no-cpu-baseline --no-profile --no-item-sync-leg > $O/stats_cfg5.log 2>&1 || exit 1
 echo "[prof] pmc fetch"; rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o f -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile --no-item-sync-leg > $O/pmc_fetch.log 2>&1 || exit 1
 echo "[prof] pmc write"; rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o w -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile --no-item-sync-leg > $O/pmc_write.log 2>&1 || exit 1
 F=$(find $O/pmc_fetch -name "f_results.db" | head -1); W=$(find $O/pmc_write -name "w_results.db" | head -1)
