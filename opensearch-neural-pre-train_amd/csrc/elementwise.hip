@@ -445,24 +445,35 @@ __global__ void embed_count_kernel(const int64_t* __restrict__ ids, int* __restr
   const long id = ids[t];
   if (id != pad_id && id >= 0 && id < V) atomicAdd(cnt + id, 1);
 }
-// off[v] = sum of cnt[0..v), off[V] = total; one workgroup, each thread a contiguous run of ids
+// off[v] = sum of cnt[0..v), off[V] = total.  One workgroup walks the ids in chunks of 1024 with coalesced loads: wave-level
+// inclusive scan (6 shuffles), the 16 wave totals scanned by every thread from LDS, a running offset carried from chunk to
+// chunk (the first form gave each thread a contiguous run of 49 ids: 196-byte strides, 75 us for 50,000 ids).
 __global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int V) {
-  __shared__ int sums[1024];
-  const int per = (V + 1023) / 1024;
-  const int v0 = threadIdx.x * per, v1 = min(V, v0 + per);
-  int s = 0;
-  for (int v = v0; v < v1; ++v) s += cnt[v];
-  sums[threadIdx.x] = s;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {                 // inclusive Hillis-Steele scan of the 1024 run sums
-    const int add = threadIdx.x >= d ? sums[threadIdx.x - d] : 0;
-    __syncthreads();
-    sums[threadIdx.x] += add;
-    __syncthreads();
+  __shared__ int wsum[2][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int run = 0;
+  for (int v0 = 0, it = 0; v0 < V; v0 += 1024, ++it) {
+    const int v = v0 + threadIdx.x;
+    const int c = v < V ? cnt[v] : 0;
+    int inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += up;
+    }
+    if (lane == 63) wsum[it & 1][wave] = inc;
+    __syncthreads();                                   // (two buffers: the next chunk's writes cannot overtake these reads)
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int t = wsum[it & 1][w];
+      if (w < wave) before += t;
+      total += t;
+    }
+    if (v < V) off[v] = run + before + inc - c;
+    run += total;
   }
-  int run = threadIdx.x ? sums[threadIdx.x - 1] : 0;
-  for (int v = v0; v < v1; ++v) { off[v] = run; run += cnt[v]; }
-  if (threadIdx.x == 1023) off[V] = sums[1023];
+  if (threadIdx.x == 0) off[V] = run;
 }
 __global__ void embed_fill_kernel(const int64_t* __restrict__ ids, const int* __restrict__ off, int* __restrict__ fill,
                                   int* __restrict__ list, int T, int V, int pad_id) {
