@@ -89,6 +89,20 @@ int snx_model_forward(const snx_model_desc* d, const void* const* params /*[host
 /* `groups` (optional): {n, (seq_begin, nseq, max_len) x n} -- consecutive sequence groups of different
  * maximum length laid end to end in ONE call (e.g. the query, positive and negative batches of a
  * training micro-step); NULL = one group of nseq sequences. */
+/* One PASS of a micro-step into a row range of a larger arena: the reference calls model(...) three times per micro-step
+ * (query, positive, negative: ref:src/train/cli/train_v33_ddp.py:339-343) and back-propagates once.  `saved`, `sparse_all`
+ * [nseq_plan, vocab] and `token_weights_all` [T_plan] are laid out for the WHOLE micro-step (snx_model_workspace_bytes(T_plan,
+ * nseq_plan, 1)); this call fills token rows [row0, row0 + T) and sequences [seq0, seq0 + nseq) from the pass's own
+ * ids / mask / pos / cu_seqlens (cu_seqlens[0] = 0), groups = NULL, flags must save for backward.  After the last pass the
+ * arena equals what one snx_model_forward over all rows (with the passes as sequence groups) leaves behind, so ONE
+ * snx_model_backward(_units) over (T_plan, nseq_plan) with the concatenated ids / mask / pos / global cu_seqlens runs the
+ * micro-step's backward on full-size launches.  row0 = seq0 = 0, T = T_plan, nseq = nseq_plan is snx_model_forward. */
+int snx_model_forward_range(const snx_model_desc* d, const void* const* params /*[host]*/, const void* wcache,
+                            const int64_t* ids, const int64_t* mask, const int32_t* cu_seqlens, const int32_t* pos,
+                            const float* rope_global, const float* rope_local, void* saved, float* sparse_all,
+                            float* token_weights_all, const int32_t* groups /*NULL for a true sub-range*/, int32_t T_plan,
+                            int32_t nseq_plan, int32_t row0, int32_t seq0, int32_t T, int32_t nseq, int32_t max_seqlen,
+                            int32_t flags, hipStream_t stream);
 
 /* Backward of the above (the autograd graph of ref:src/model/splade_modern.py:69-86 and of the HF
  * encoder): g_sparse [nseq, vocab] fp32 = dL/d sparse_repr; every grads[i] (fp32, same shape as
@@ -114,6 +128,17 @@ int snx_model_backward_units(const snx_model_desc* d, const void* const* params 
                              const float* g_sparse, void* scratch, const int32_t* groups /*[host] or NULL*/,
                              int32_t T, int32_t nseq, int32_t max_seqlen, int32_t unit_begin, int32_t unit_end,
                              hipStream_t notify, hipStream_t stream);
+
+/* ... over the first T rows / nseq sequences of an arena and scratch laid out for (T_plan, nseq_plan): the backward of a
+ * micro-step that placed fewer passes than planned (snx_model_forward_range); `scratch` needs
+ * snx_model_bwd_workspace_bytes(T_plan, nseq_plan, max_seqlen). */
+int snx_model_backward_units_range(const snx_model_desc* d, const void* const* params /*[host]*/,
+                                   void* const* grads /*[host]*/, const void* wcache, const int64_t* ids,
+                                   const int64_t* mask, const int32_t* cu_seqlens, const int32_t* pos,
+                                   const float* rope_global, const float* rope_local, const void* saved,
+                                   const float* g_sparse, void* scratch, const int32_t* groups /*[host] or NULL*/,
+                                   int32_t T_plan, int32_t nseq_plan, int32_t T, int32_t nseq, int32_t max_seqlen,
+                                   int32_t unit_begin, int32_t unit_end, hipStream_t notify, hipStream_t stream);
 
 /* ---- fp32 execution (csrc/f32_path.hip): what the reference computes OUTSIDE torch.autocast -- a bare
  * SPLADEModernBERT.forward (ref:src/model/splade_modern.py:50-88), its inference encoder (ref:benchmark/encoders.py:

@@ -346,63 +346,107 @@ extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* par
                                  const int32_t* pos, const float* rope_global, const float* rope_local, void* saved,
                                  float* sparse, float* token_weights, const int32_t* groups, int32_t T,
                                  int32_t nseq, int32_t max_seqlen, int32_t flags, hipStream_t st) {
+  return snx_model_forward_range(d, params, wcache, ids, mask, cu_seqlens, pos, rope_global, rope_local, saved, sparse,
+                                 token_weights, groups, T, nseq, 0, 0, T, nseq, max_seqlen, flags, st);
+}
+
+// One PASS of a micro-step into a row range of a larger arena (the reference's call pattern, ref:train_v33_ddp.py:339-343:
+// query, positive and negative batches are three model(...) calls).  The arena, `sparse` and `token_weights` are laid out
+// for T_plan token rows / nseq_plan sequences (the whole micro-step); this call fills rows [row0, row0 + T) and sequences
+// [seq0, seq0 + nseq) from the pass's OWN ids / mask / pos / cu_seqlens (cu_seqlens[0] = 0).  Every per-token buffer is
+// row-major, so a pass is the same kernels on shifted pointers; only the attention LSE is head-major ([heads, T_plan]) and
+// keeps T_plan as its stride.  After the last pass the arena is exactly what one fused snx_model_forward over all rows
+// leaves behind, and ONE snx_model_backward over (T_plan, nseq_plan) back-propagates the micro-step.
+extern "C" int snx_model_forward_range(const snx_model_desc* d, const void* const* params, const void* wcache,
+                                       const int64_t* ids, const int64_t* mask, const int32_t* cu_seqlens,
+                                       const int32_t* pos, const float* rope_global, const float* rope_local,
+                                       void* saved, float* sparse_all, float* token_weights_all, const int32_t* groups,
+                                       int32_t T_plan, int32_t nseq_plan, int32_t row0, int32_t seq0, int32_t T,
+                                       int32_t nseq, int32_t max_seqlen, int32_t flags, hipStream_t st) {
   if (!desc_ok(d)) return SNX_E_SHAPE;
-  if (!params || !wcache || !ids || !mask || !cu_seqlens || !pos || !rope_global || !rope_local || !saved || !sparse ||
-      !token_weights || T <= 0 || nseq <= 0 || max_seqlen <= 0)
+  if (!params || !wcache || !ids || !mask || !cu_seqlens || !pos || !rope_global || !rope_local || !saved || !sparse_all ||
+      !token_weights_all || T <= 0 || nseq <= 0 || max_seqlen <= 0)
     return SNX_E_ARG;
+  if (row0 < 0 || seq0 < 0 || (long)row0 + T > T_plan || (long)seq0 + nseq > nseq_plan) return SNX_E_ARG;
+  const bool ranged = T != T_plan || nseq != nseq_plan;
+  if (ranged && groups) return SNX_E_ARG;                  // a pass of a larger arena is one sequence group
   const bool save = (flags & SNX_FWD_SAVE_FOR_BACKWARD) != 0;
+  if (ranged && !save) return SNX_E_ARG;                   // (the no-save plan reuses buffers across layers: nothing to share)
   CachePlan c;
   SavedPlan s;
-  if (!plan_cache(d, c) || !plan_saved(d, T, nseq, save, s)) return SNX_E_SHAPE;
+  if (!plan_cache(d, c) || !plan_saved(d, T_plan, nseq_plan, save, s)) return SNX_E_SHAPE;
   PIdx p{d->layers};
   const char* wc = (const char*)wcache;
-  char* sv = (char*)saved;
   const int H = d->hidden, I = d->inter, V = d->vocab, L = d->layers;
+  // `sv + s.x` below = the pass's first row of buffer x: SavedView shifts a buffer offset by row0 rows of that buffer
+  struct SavedView {
+    char* base; size_t row0;
+    char* at(size_t off, size_t row_bytes) const { return base + off + row0 * row_bytes; }
+  } view{(char*)saved, (size_t)row0};
+  float* sparse = sparse_all + (size_t)seq0 * V;
+  float* token_weights = token_weights_all + row0;
   auto F = [&](int idx) { return (const float*)params[idx]; };
-  auto hbuf = [&](int i) { return (float*)(sv + s.h[i]); };
+  auto hbuf = [&](int i) { return (float*)view.at(s.h[i], (size_t)H * 4); };
+  // shifted views of the per-token bf16 buffers (named as the plan names them)
+  struct Sv {
+    const SavedView& v; const SavedPlan& s; size_t H, I;
+    char* x_attn(int l) const { return v.at(s.x_attn[l], H * 2); }
+    char* x_mlp(int l) const { return v.at(s.x_mlp[l], H * 2); }
+    char* qkv(int l) const { return v.at(s.qkv[l], 3 * H * 2); }
+    char* attn(int l) const { return v.at(s.attn[l], H * 2); }
+    char* lse(int l) const { return v.at(s.lse[l], 4); }          // [heads, T_plan]: first token of the pass in head 0
+    char* u(int l) const { return v.at(s.u[l], 2 * I * 2); }
+    char* y(int l) const { return v.at(s.y[l], I * 2); }
+    char* xf() const { return v.at(s.xf, H * 2); }
+    char* dd() const { return v.at(s.dd, H * 2); }
+    char* hd() const { return v.at(s.hd, H * 2); }
+    char* rope_rows(int k) const { return v.at(s.rope_rows[k], 256); }
+  } sv{view, s, (size_t)H, (size_t)I};
+  uint32_t* keys = (uint32_t*)((char*)saved + s.keys) + (size_t)seq0 * V;
+  char* rowpart = (char*)saved + s.rowpart;
 
   const double TH = (double)T * H;
-  { PROF(PC_EMBED, TH * 10); RC(snx_embed_ln_fwd(ids, F(p.tok_emb()), F(p.emb_norm()), hbuf(0), sv + s.x_attn[0], T, H, d->ln_eps, st)); }
+  { PROF(PC_EMBED, TH * 10); RC(snx_embed_ln_fwd(ids, F(p.tok_emb()), F(p.emb_norm()), hbuf(0), sv.x_attn(0), T, H, d->ln_eps, st)); }
   // positions -> (cos, sin) rows once per pass and theta: the 22 Wqkv write-backs then read them without the dependent load
   { PROF(PC_ROPE, 2.0 * T * 512);
-    RC(snx_rope_rows(rope_global, pos, (float*)(sv + s.rope_rows[0]), T, st));
-    RC(snx_rope_rows(rope_local, pos, (float*)(sv + s.rope_rows[1]), T, st)); }
+    RC(snx_rope_rows(rope_global, pos, (float*)sv.rope_rows(0), T, st));
+    RC(snx_rope_rows(rope_local, pos, (float*)sv.rope_rows(1), T, st)); }
   // "resid_in_ln": the Wo GEMMs store their bf16 result (ybuf: the head's dense buffer, free until the layers are done)
   // and the residual add h + float(y) happens inside the LayerNorm that follows every one of them -- the same bits as the
   // GEMM's residual epilogue, the fp32 stream's read + write moved from an MFMA-bound kernel to an HBM-bound one.
   const bool ril = g_snx_cfg.resid_in_ln != 0;
-  char* ybuf = sv + s.dd;
+  char* ybuf = sv.dd();
   for (int l = 0; l < L; ++l) {
     const bool global = (l % d->global_every) == 0;
-    if (l > 0 && !ril) { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l), F(p.attn_norm(l)), sv + s.x_attn[l], T, H, d->ln_eps, st)); }
+    if (l > 0 && !ril) { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l), F(p.attn_norm(l)), sv.x_attn(l), T, H, d->ln_eps, st)); }
     { PROF(PC_GEMM_NT, 2.0 * T * 3 * H * H);      // Wqkv + RoPE fused
-      RC(snx_gemm_nt_rope_rows(sv + s.x_attn[l], wc + c.wqkv[l], sv + s.qkv[l], global ? rope_global : rope_local, pos,
-                               (const float*)(sv + s.rope_rows[global ? 0 : 1]), 2 * H, T, 3 * H, H, st)); }
+      RC(snx_gemm_nt_rope_rows(sv.x_attn(l), wc + c.wqkv[l], sv.qkv(l), global ? rope_global : rope_local, pos,
+                               (const float*)sv.rope_rows(global ? 0 : 1), 2 * H, T, 3 * H, H, st)); }
     { PROF(PC_ATTN_FWD, 4.0 * H * attn_pairs(groups, nseq, max_seqlen, global ? -1 : d->window));
-      RC(snx_attn_fwd_ex(sv + s.qkv[l], cu_seqlens, mask, sv + s.attn[l], (float*)(sv + s.lse[l]), groups, T, nseq,
+      RC(snx_attn_fwd_ex(sv.qkv(l), cu_seqlens, mask, sv.attn(l), (float*)sv.lse(l), groups, T_plan /* LSE stride */, nseq,
                          max_seqlen, d->heads, d->head_dim, global ? -1 : d->window, st)); }
     if (ril) {
-      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * H); RC(snx_gemm_nt_bf16(sv + s.attn[l], wc + c.wo[l], ybuf, T, H, H, st)); }
-      { PROF(PC_LN_FWD, TH * 12); RC(snx_ln_fwd_add(hbuf(2 * l), ybuf, F(p.mlp_norm(l)), hbuf(2 * l + 1), sv + s.x_mlp[l], T, H, d->ln_eps, st)); }
+      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * H); RC(snx_gemm_nt_bf16(sv.attn(l), wc + c.wo[l], ybuf, T, H, H, st)); }
+      { PROF(PC_LN_FWD, TH * 12); RC(snx_ln_fwd_add(hbuf(2 * l), ybuf, F(p.mlp_norm(l)), hbuf(2 * l + 1), sv.x_mlp(l), T, H, d->ln_eps, st)); }
     } else {
-      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * H); RC(snx_gemm_nt_resid(sv + s.attn[l], wc + c.wo[l], hbuf(2 * l), hbuf(2 * l + 1), T, H, H, st)); }
-      { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l + 1), F(p.mlp_norm(l)), sv + s.x_mlp[l], T, H, d->ln_eps, st)); }
+      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * H); RC(snx_gemm_nt_resid(sv.attn(l), wc + c.wo[l], hbuf(2 * l), hbuf(2 * l + 1), T, H, H, st)); }
+      { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * l + 1), F(p.mlp_norm(l)), sv.x_mlp(l), T, H, d->ln_eps, st)); }
     }
     { PROF(PC_GEMM_NT, 2.0 * T * 2 * I * H);      // Wi + GeGLU fused (u kept in the interleaved column order)
-      RC(snx_gemm_nt_geglu_fwd(sv + s.x_mlp[l], wc + c.wi[l], sv + s.u[l], sv + s.y[l], T, 2 * I, H, st)); }
+      RC(snx_gemm_nt_geglu_fwd(sv.x_mlp(l), wc + c.wi[l], sv.u(l), sv.y(l), T, 2 * I, H, st)); }
     if (ril) {
-      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * I); RC(snx_gemm_nt_bf16(sv + s.y[l], wc + c.wom[l], ybuf, T, H, I, st)); }
+      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * I); RC(snx_gemm_nt_bf16(sv.y(l), wc + c.wom[l], ybuf, T, H, I, st)); }
       const bool last = l + 1 == L;
       { PROF(PC_LN_FWD, TH * 12);
         RC(snx_ln_fwd_add(hbuf(2 * l + 1), ybuf, F(last ? p.final_norm() : p.attn_norm(l + 1)), hbuf(2 * l + 2),
-                          last ? sv + s.xf : sv + s.x_attn[l + 1], T, H, d->ln_eps, st)); }
+                          last ? sv.xf() : sv.x_attn(l + 1), T, H, d->ln_eps, st)); }
     } else {
-      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * I); RC(snx_gemm_nt_resid(sv + s.y[l], wc + c.wom[l], hbuf(2 * l + 1), hbuf(2 * l + 2), T, H, I, st)); }
+      { PROF(PC_GEMM_NT_RESID, 2.0 * TH * I); RC(snx_gemm_nt_resid(sv.y(l), wc + c.wom[l], hbuf(2 * l + 1), hbuf(2 * l + 2), T, H, I, st)); }
     }
   }
-  if (!ril) { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * L), F(p.final_norm()), sv + s.xf, T, H, d->ln_eps, st)); }
-  { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(sv + s.xf, wc + c.dense, sv + s.dd, T, H, H, st)); }
-  { PROF(PC_LN_FWD, TH * 4); RC(snx_gelu_ln_fwd(sv + s.dd, F(p.head_norm()), sv + s.hd, T, H, d->ln_eps, st)); }
+  if (!ril) { PROF(PC_LN_FWD, TH * 6); RC(snx_ln_fwd(hbuf(2 * L), F(p.final_norm()), sv.xf(), T, H, d->ln_eps, st)); }
+  { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(sv.xf(), wc + c.dense, sv.dd(), T, H, H, st)); }
+  { PROF(PC_LN_FWD, TH * 4); RC(snx_gelu_ln_fwd(sv.dd(), F(p.head_norm()), sv.hd(), T, H, d->ln_eps, st)); }
   {
     // Sequence groups (e.g. 64-token queries and 256-token documents concatenated in one call)
     // get the decoder tile height that fits their length; groups = {n, (seq_begin, nseq, max_len)*n}.
@@ -413,9 +457,9 @@ extern "C" int snx_model_forward(const snx_model_desc* d, const void* const* par
     for (int i = 0; i < g[0]; ++i) {
       const int sb = g[1 + 3 * i], ns = g[2 + 3 * i], ml = g[3 + 3 * i];
       if (sb < 0 || ns <= 0 || sb + ns > nseq || ml <= 0 || ml > max_seqlen) return SNX_E_ARG;
-      RC(snx_decoder_splade_fwd_ex(sv + s.hd, wc + c.emb, F(p.dec_bias()), cu_seqlens + sb, mask,
-                                   sparse + (size_t)sb * V, (uint32_t*)(sv + s.keys) + (size_t)sb * V, token_weights,
-                                   sv + s.rowpart, T, ns, ml, V, H, i + 1 == g[0], st));
+      RC(snx_decoder_splade_fwd_ex(sv.hd(), wc + c.emb, F(p.dec_bias()), cu_seqlens + sb, mask,
+                                   sparse + (size_t)sb * V, keys + (size_t)sb * V, token_weights,
+                                   rowpart, T, ns, ml, V, H, i + 1 == g[0], st));
     }
   }
   return SNX_OK;
@@ -432,16 +476,31 @@ extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* con
                                         void* scratch, const int32_t* groups, int32_t T, int32_t nseq,
                                         int32_t max_seqlen, int32_t unit_begin, int32_t unit_end, hipStream_t notify,
                                         hipStream_t st) {
+  return snx_model_backward_units_range(d, params, grads, wcache, ids, mask, cu_seqlens, pos, rope_global, rope_local, saved,
+                                        g_sparse, scratch, groups, T, nseq, T, nseq, max_seqlen, unit_begin, unit_end,
+                                        notify, st);
+}
+
+// The backward over the first T rows / nseq sequences of an arena (and a scratch buffer) laid out for T_plan rows /
+// nseq_plan sequences: what is left to back-propagate when a micro-step placed fewer passes into its arena than the
+// pattern promised (snx_model_forward_range).  T = T_plan, nseq = nseq_plan is the ordinary backward.
+extern "C" int snx_model_backward_units_range(const snx_model_desc* d, const void* const* params, void* const* grads,
+                                              const void* wcache, const int64_t* ids, const int64_t* mask,
+                                              const int32_t* cu_seqlens, const int32_t* pos, const float* rope_global,
+                                              const float* rope_local, const void* saved, const float* g_sparse,
+                                              void* scratch, const int32_t* groups, int32_t T_plan, int32_t nseq_plan,
+                                              int32_t T, int32_t nseq, int32_t max_seqlen, int32_t unit_begin,
+                                              int32_t unit_end, hipStream_t notify, hipStream_t st) {
   if (!desc_ok(d)) return SNX_E_SHAPE;
   if (!params || !grads || !wcache || !ids || !mask || !cu_seqlens || !pos || !rope_global || !rope_local || !saved ||
-      !g_sparse || !scratch || T <= 0 || nseq <= 0 || max_seqlen <= 0)
+      !g_sparse || !scratch || T <= 0 || nseq <= 0 || max_seqlen <= 0 || T > T_plan || nseq > nseq_plan)
     return SNX_E_ARG;
   if (unit_begin < 0 || unit_end > d->layers + 2 || unit_begin >= unit_end) return SNX_E_ARG;
   CachePlan c;
   SavedPlan s;
   BwdPlan b;
-  if (!plan_cache(d, c) || !plan_saved(d, T, nseq, true, s)) return SNX_E_SHAPE;
-  plan_bwd(d, T, nseq, max_seqlen, b);
+  if (!plan_cache(d, c) || !plan_saved(d, T_plan, nseq_plan, true, s)) return SNX_E_SHAPE;
+  plan_bwd(d, T_plan, nseq_plan, max_seqlen, b);
   PIdx p{d->layers};
   const char* wc = (const char*)wcache;
   const char* sv = (const char*)saved;
@@ -516,8 +575,9 @@ extern "C" int snx_model_backward_units(const snx_model_desc* d, const void* con
     { PROF(PC_GEMM_NT, 2.0 * TH * H); RC(snx_gemm_nt_bf16(Q, wc + c.wo_t[l], Bb, T, H, H, st)); }    // d(attn out)
     { PROF(PC_ATTN_BWD, 10.0 * H * pairs);
       RC(snx_attn_bwd_ex(sv + s.qkv[l], sv + s.attn[l], Bb, (const float*)(sv + s.lse[l]), cu_seqlens, mask,
-                         (float*)(sc + b.delta), Dq, global ? rope_global : rope_local, pos, groups, T, nseq,
-                         max_seqlen, d->heads, d->head_dim, global ? -1 : d->window, st)); }      // inverse RoPE fused
+                         (float*)(sc + b.delta), Dq, global ? rope_global : rope_local, pos, groups,
+                         T_plan /* LSE / delta stride */, nseq, max_seqlen, d->heads, d->head_dim, global ? -1 : d->window,
+                         st)); }                                                                  // inverse RoPE fused
     RC(join(g_side.done[k ^ 1]));                  // layer l + 1's grouped launch has finished reading Pn
     { PROF(PC_GEMM_NT, 2.0 * TH * 3 * H); RC(snx_gemm_nt_bf16(Dq, wc + c.wqkv_t[l], Pn, T, H, 3 * H, st)); }   // dx [T,H]
     // the four weight gradients of the layer: dWo(mlp) = P^T y, dWi = du^T x_mlp, dWo(attn) = Q^T attn, dWqkv = dqkv^T x_attn

@@ -72,6 +72,8 @@ SIGNATURES = {
     "snx_weight_cache_bytes": (SZ, [P]),
     "snx_weight_cache_refresh": (I32, [P, P, P, P]),
     "snx_model_forward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P]),
+    "snx_model_forward_range": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, P]),
+    "snx_model_backward_units_range": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, P, P]),
     "snx_model_backward": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P]),
     "snx_model_backward_units": (I32, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P]),
     "snx_sparse_topk": (I32, [P, P, P, P, P, P, I32, I32, I32, I32, P]),

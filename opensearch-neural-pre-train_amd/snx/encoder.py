@@ -100,6 +100,13 @@ class EncoderRuntime:
         self.last_ctx = None
         # bucketed gradient exchange overlapped with the backward (snx.dist.BucketedGradSync); armed per call
         self.grad_sync = None
+        # micro-step arena (StepArena below): the call pattern learnt from the previous micro-step, the shapes seen since the
+        # last completed backward, saving forwards not yet back-propagated, the arena being filled
+        self.step_arena_on = os.environ.get("SNX_STEP_ARENA", "1") != "0"
+        self._pattern: Optional[tuple] = None
+        self._observed: list = []
+        self._open_nodes = 0
+        self._arena: Optional["StepArena"] = None
 
     # ------------------------------------------------------------------ parameter plumbing
     def _device(self):
@@ -242,6 +249,26 @@ class EncoderRuntime:
             return forced
         return "bf16" if (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16) else "fp32"
 
+    def _layout(self, shapes, dev):
+        """(cu_seqlens int32 [nseq + 1], pos int32 [T], groups C array) of dense [B_i, S_i] batches laid end to end (cached)."""
+        key = (tuple(shapes), str(dev))
+        lay = self._seq_cache.get(key)
+        if lay is not None:
+            self._seq_cache.move_to_end(key)
+            return lay
+        cu, pos, groups, t0, s0 = [0], [], [len(shapes)], 0, 0
+        for B, S in shapes:
+            cu += [t0 + (b + 1) * S for b in range(B)]
+            pos.append(torch.arange(S, dtype=torch.int32).repeat(B))
+            groups += [s0, B, S]
+            t0 += B * S
+            s0 += B
+        lay = (torch.tensor(cu, dtype=torch.int32).to(dev), torch.cat(pos).to(dev), (C.c_int32 * len(groups))(*groups))
+        self._seq_cache[key] = lay
+        while len(self._seq_cache) > _SEQ_CACHE_ENTRIES:
+            self._seq_cache.popitem(last=False)
+        return lay
+
     def forward_many_impl(self, pairs, save: bool, lengths=None):
         """One native forward over several [B_i, S_i] batches laid end to end (sequence groups).
         -> sparse [sum B_i, V], token_weights [sum B_i*S_i] (flat, padded layout), arena, aux.
@@ -296,23 +323,7 @@ class EncoderRuntime:
             T = t0
             smax = max(groups[3 + 3 * i] for i in range(len(shapes)))
         else:
-            key = (tuple(shapes), str(dev))
-            lay = self._seq_cache.get(key)
-            if lay is not None:
-                self._seq_cache.move_to_end(key)
-            if lay is None:
-                cu, pos, groups, t0, s0 = [0], [], [len(shapes)], 0, 0
-                for B, S in shapes:
-                    cu += [t0 + (b + 1) * S for b in range(B)]
-                    pos.append(torch.arange(S, dtype=torch.int32).repeat(B))
-                    groups += [s0, B, S]
-                    t0 += B * S
-                    s0 += B
-                lay = (torch.tensor(cu, dtype=torch.int32).to(dev), torch.cat(pos).to(dev),
-                       (C.c_int32 * len(groups))(*groups))
-                self._seq_cache[key] = lay
-                while len(self._seq_cache) > _SEQ_CACHE_ENTRIES:
-                    self._seq_cache.popitem(last=False)
+            lay = self._layout(shapes, dev)
             cu, pos, groups = lay
             T = T_pad
             smax = max(S for _, S in shapes)
@@ -352,8 +363,11 @@ class EncoderRuntime:
         keys = saved[off:off + B * self.geom.vocab_size * 4].view(torch.int32).view(B, -1).to(torch.int64) & 0xFFFFFFFF
         return 0xFFFF - (keys & 0xFFFF)
 
-    def backward_impl(self, saved: torch.Tensor, aux, g_sparse: torch.Tensor, sync_token=None):
+    def backward_impl(self, saved: torch.Tensor, aux, g_sparse: torch.Tensor, sync_token=None, plan=None):
+        """``plan`` = (T_plan, nseq_plan): `saved` was laid out for that many rows / sequences (a micro-step arena that
+        holds fewer passes than planned); default: the arena of exactly these T rows."""
         ids, mask, cu, pos, rg, rl, T, B, S, groups, fp32 = aux  # B = total sequences, S = longest
+        Tp, Bp = plan if plan is not None else (T, B)
         dev = self._device()
         if g_sparse.shape != (B, self.geom.vocab_size):
             raise ValueError("bad gradient shape")
@@ -377,16 +391,18 @@ class EncoderRuntime:
                 args32 = (C.byref(self._desc), self._param_ptrs(), self._grad_ptrs(grads), _p(ids), _p(mask), _p(cu), _p(pos),
                           _p(rg), _p(rl), _p(saved), _p(g), _p(scratch), T, B)
             else:
-                nbytes = fn("snx_model_bwd_workspace_bytes")(C.byref(self._desc), T, B, S)
+                nbytes = fn("snx_model_bwd_workspace_bytes")(C.byref(self._desc), Tp, Bp, S)
                 scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                 args = (C.byref(self._desc), self._param_ptrs(), self._grad_ptrs(grads), _p(self._weights()), _p(ids),
-                        _p(mask), _p(cu), _p(pos), _p(rg), _p(rl), _p(saved), _p(g), _p(scratch), groups, T, B, S)
+                        _p(mask), _p(cu), _p(pos), _p(rg), _p(rl), _p(saved), _p(g), _p(scratch), groups, Tp, Bp, T, B, S)
+                n_units = self.geom.num_hidden_layers + 2
 
             def run_all():
                 if fp32:
                     check(fn("snx_model_backward_f32")(*args32, _stream()), "snx_model_backward_f32")
                 else:
-                    check(fn("snx_model_backward")(*args, _stream()), "snx_model_backward")
+                    check(fn("snx_model_backward_units_range")(*args, 0, n_units, None, _stream()),
+                          "snx_model_backward_units_range")
 
             def run_units(ub, ue):
                 if fp32:                        # one native call; the exchange stream then waits for the launch stream
@@ -395,8 +411,8 @@ class EncoderRuntime:
                     sync.stream.wait_stream(torch.cuda.current_stream(dev))
                     return
                 # the native call makes the exchange stream wait for the launch stream and the weight-gradient stream
-                check(fn("snx_model_backward_units")(*args, ub, ue, C.c_void_p(sync.stream.cuda_stream), _stream()),
-                      "snx_model_backward_units")
+                check(fn("snx_model_backward_units_range")(*args, ub, ue, C.c_void_p(sync.stream.cuda_stream), _stream()),
+                      "snx_model_backward_units_range")
 
             if sync is None:
                 run_all()
@@ -415,6 +431,50 @@ class EncoderRuntime:
                     if reserve:
                         fn("snx_set_reserved_cus")(0)
         return ret
+
+    # ------------------------------------------------------------------ micro-step arena
+    def _arena_eligible(self) -> bool:
+        return (self.step_arena_on and not self.keep_last_ctx and self.precision() == "bf16" and
+                self.geom.bf16_unsupported_reason() is None)
+
+    def step_arena_observe(self, ids: torch.Tensor) -> bool:
+        """A single-batch saving forward on the ordinary path: part of the pattern being learnt.  True: its backward
+        reports back (step_arena_backward_done)."""
+        if not self._arena_eligible():
+            self._pattern, self._observed, self._open_nodes = None, [], 0
+            return False
+        self._observed.append((int(ids.shape[0]), int(ids.shape[1])))
+        self._open_nodes += 1
+        return True
+
+    def step_arena_backward_done(self) -> None:
+        self._open_nodes -= 1
+        if self._open_nodes == 0:
+            # every forward made since the last completed backward has been back-propagated: that was one micro-step
+            self._pattern = tuple(self._observed) if 2 <= len(self._observed) <= 8 else None
+            self._observed = []
+
+    def step_arena_place(self, ids: torch.Tensor, mask: torch.Tensor):
+        """The next pass of the learnt pattern -> (sparse [B, V], token_weights [B*S], arena, index), or None when this call
+        does not continue the pattern (then it runs on the ordinary path and the pattern is learnt anew)."""
+        if self._pattern is None or not self._arena_eligible() or ids.dim() != 2 or mask.shape != ids.shape or \
+                ids.device != self._device() or mask.device != ids.device:
+            return None
+        a = self._arena
+        shape = (int(ids.shape[0]), int(ids.shape[1]))
+        if a is not None and a.closed:                       # backwards of the previous micro-step still outstanding
+            self._pattern = None
+            return None
+        k = 0 if a is None else a.placed
+        if self._open_nodes or k >= len(self._pattern) or shape != self._pattern[k]:
+            if a is not None:
+                a.broken = True                              # the passes placed so far back-propagate as a prefix
+                self._arena = None
+            self._pattern = None
+            return None
+        if a is None:
+            a = self._arena = StepArena(self, self._pattern)
+        return a.place(ids, mask)
 
     def __call__(self, input_ids, attention_mask):
         (out,) = self.forward_many([(input_ids, attention_mask)])
@@ -442,6 +502,135 @@ class EncoderRuntime:
             out.append((sp, tw[t0:t0 + B * S].view(B, S)))
             t0 += B * S
         return out
+
+
+class StepArena:
+    """The forwards of ONE micro-step placed in ONE activation arena, back-propagated by ONE native backward.
+
+    The reference's loop calls model(...) three times per micro-step (query, positive, negative:
+    ref:src/train/cli/train_v33_ddp.py:339-343) and back-propagates once (:364).  Run as three independent passes that costs
+    10 ms per micro-step of DEVICE time over the fused pass (402 + 69 GEMM launches of a third of the rows each:
+    profiles/r05_caller_breakdown.txt), two thirds of it in the backward.  Without touching the caller: the runtime learns
+    the sequence of (batch, seq_len) shapes of one micro-step, and in the next one lays the arena out for the whole pattern
+    and lets every model(...) call fill its row range (snx_model_forward_range: the same kernels on shifted pointers, so
+    the outputs are bit-identical to a stand-alone pass).  The backward calls of the three autograd nodes only hand in
+    their output gradients; the LAST one to report runs the fused native backward over the whole arena -- the launches
+    (and the bucketed gradient exchange) of the fused micro-step.  A call that does not continue the pattern falls back to
+    the ordinary path; the passes already placed back-propagate as a prefix of the arena; the pattern is learnt anew.
+
+    Limits (documented, checked): bf16 path, dense [B, S] batches (no `lengths`), every placed pass must take part in the
+    loss -- if the autograd engine finishes a backward pass with a placed node unreported, the remaining gradient is
+    back-propagated with zeros for it in the flat-gradient mode and raised as an error otherwise."""
+
+    def __init__(self, rt: "EncoderRuntime", pattern):
+        self.rt, self.pattern = rt, tuple(pattern)
+        dev = rt._device()
+        self.dev = dev
+        self.row0, self.seq0 = [0], [0]
+        for B, S in self.pattern:
+            self.row0.append(self.row0[-1] + B * S)
+            self.seq0.append(self.seq0[-1] + B)
+        self.T, self.nseq = self.row0[-1], self.seq0[-1]
+        self.smax = max(S for _, S in self.pattern)
+        V = rt.geom.vocab_size
+        with torch.cuda.device(dev):
+            nbytes = fn("snx_model_workspace_bytes")(C.byref(rt._desc), self.T, self.nseq, 1)
+            self.saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.sparse = torch.empty((self.nseq, V), dtype=torch.float32, device=dev)
+            self.tw = torch.empty((self.T,), dtype=torch.float32, device=dev)
+            self.ids = torch.empty((self.T,), dtype=torch.int64, device=dev)
+            self.mask = torch.empty((self.T,), dtype=torch.int64, device=dev)
+        self.placed = self.reported = 0
+        self.grads = [None] * len(self.pattern)
+        self.closed = self.broken = self.done = False
+        self.last_token = None
+
+    def place(self, ids: torch.Tensor, mask: torch.Tensor):
+        rt, k = self.rt, self.placed
+        B, S = self.pattern[k]
+        r0, s0, T = self.row0[k], self.seq0[k], B * S
+        cu, pos, _ = rt._layout([(B, S)], self.dev)
+        ids_k, mask_k = self.ids[r0:r0 + T], self.mask[r0:r0 + T]
+        ids_k.copy_(ids.reshape(-1))
+        mask_k.copy_(mask.reshape(-1))
+        hd = rt.geom.hidden_size // rt.geom.num_attention_heads
+        with torch.cuda.device(self.dev):
+            rg, rl = rt._rope_tables(max(self.smax, 64), self.dev, hd)
+            check(fn("snx_model_forward_range")(C.byref(rt._desc), rt._param_ptrs(), _p(rt._weights()), _p(ids_k), _p(mask_k),
+                                                _p(cu), _p(pos), _p(rg), _p(rl), _p(self.saved), _p(self.sparse), _p(self.tw),
+                                                None, self.T, self.nseq, r0, s0, T, B, S, SNX_FWD_SAVE_FOR_BACKWARD,
+                                                _stream()), "snx_model_forward_range")
+        self.placed += 1
+        if self.placed == len(self.pattern):
+            rt._arena = None                                 # complete: the next forward opens a new micro-step
+        return self.sparse[s0:s0 + B], self.tw[r0:r0 + T], self, k
+
+    def routing_rows(self, k: int) -> torch.Tensor:
+        """Arg-max sequence position per (sequence, vocab) entry of pass k (as EncoderRuntime.routing_rows)."""
+        rt, V = self.rt, self.rt.geom.vocab_size
+        B = self.pattern[k][0]
+        off = fn("snx_model_keys_offset")(C.byref(rt._desc), self.T, self.nseq) + self.seq0[k] * V * 4
+        keys = self.saved[off:off + B * V * 4].view(torch.int32).view(B, -1).to(torch.int64) & 0xFFFFFFFF
+        return 0xFFFF - (keys & 0xFFFF)
+
+    def report(self, k: int, g: Optional[torch.Tensor], token):
+        """Backward of node k: hand in dL/d sparse_k.  Returns the parameter gradients from the LAST node to report
+        (None in the flat-gradient mode, where the native backward accumulates in place)."""
+        rt = self.rt
+        if not self.closed:
+            self.closed = True                               # no further pass can join; the engine tells us when it is done
+            if rt._arena is self:
+                rt._arena = None
+            torch.autograd.Variable._execution_engine.queue_callback(self._engine_done)
+        self.grads[k] = g
+        self.reported += 1
+        sync = rt.grad_sync if (rt.direct_grads and rt.grad_sync is not None) else None
+        if self.reported < self.placed:
+            if sync is not None:
+                sync.claim_backward(token)                   # hands the token back; never the last one outstanding
+            return None
+        return self._run(token)
+
+    def _run(self, token):
+        rt, n = self.rt, self.placed
+        self.done = True
+        shapes = list(self.pattern[:n])
+        T, nseq = self.row0[n], self.seq0[n]
+        V = rt.geom.vocab_size
+        parts = [g.to(torch.float32) if g is not None else torch.zeros((b, V), dtype=torch.float32, device=self.dev)
+                 for g, (b, _) in zip(self.grads[:n], shapes)]
+        g_all = _gather_rows(parts, [b for b, _ in shapes], V, self.dev)
+        cu, pos, groups = rt._layout(shapes, self.dev)
+        hd = rt.geom.hidden_size // rt.geom.num_attention_heads
+        rg, rl = rt._rope_tables(max(self.smax, 64), self.dev, hd)
+        aux = (self.ids[:T], self.mask[:T], cu, pos, rg, rl, T, nseq, max(s for _, s in shapes),
+               groups if n > 1 else None, False)
+        grads = rt.backward_impl(self.saved, aux, g_all, token, plan=(self.T, self.nseq))
+        self.saved = None
+        if not self.broken and n == len(self.pattern):
+            rt._pattern = self.pattern                       # the pattern held: keep it for the next micro-step
+        self.grads = []
+        return grads
+
+    def _engine_done(self):
+        """End of the autograd engine's backward pass: a placed pass that never reported took no part in the loss."""
+        if self.done:
+            return
+        rt = self.rt
+        rt._pattern = None
+        if not rt.direct_grads:
+            raise RuntimeError("snx: a model(...) output of this micro-step took no part in the loss, so its backward never "
+                               "ran and the deferred backward of the micro-step arena cannot return its gradients through "
+                               "autograd; set SNX_STEP_ARENA=0 for such loops")
+        sync = rt.grad_sync
+        token = None
+        if sync is not None and sync.armed:
+            # the unreported nodes still hold tokens: give them back so that this backward is the last outstanding one
+            missing = self.placed - self.reported
+            for _ in range(missing - 1):
+                sync.claim_backward(sync.epoch)
+            token = sync.epoch
+        self._run(token)
 
 
 def _gather_rows(gs, rows, vocab: int, device) -> torch.Tensor:
@@ -477,8 +666,18 @@ class _SpladeEncodeFn(torch.autograd.Function):
     def forward(ctx, rt: EncoderRuntime, n_pairs: int, lengths, *args):
         pairs = [(args[2 * i], args[2 * i + 1]) for i in range(n_pairs)]
         ctx.n_in = 2 * n_pairs + 1
+        ctx.rt, ctx.arena, ctx.counted = rt, None, False
+        if n_pairs == 1 and lengths is None:
+            placed = rt.step_arena_place(pairs[0][0], pairs[0][1])
+            if placed is not None:                       # this pass went into the micro-step's shared arena
+                sparse, tw, ctx.arena, ctx.k = placed
+                ctx.sync_token = rt.grad_sync.on_forward() if (rt.direct_grads and rt.grad_sync is not None) else None
+                ctx.mark_non_differentiable(tw)
+                ctx.rows, ctx.vocab = [sparse.shape[0]], sparse.shape[1]
+                return sparse, tw
+            ctx.counted = rt.step_arena_observe(pairs[0][0])
         sparse, tw, saved, aux = rt.forward_many_impl(pairs, save=True, lengths=lengths)
-        ctx.rt, ctx.saved_arena, ctx.aux = rt, saved, aux
+        ctx.saved_arena, ctx.aux = saved, aux
         # an armed micro-step counts its saving forwards: only the backward of the last outstanding one exchanges
         ctx.sync_token = rt.grad_sync.on_forward() if (rt.direct_grads and rt.grad_sync is not None) else None
         if rt.keep_last_ctx:
@@ -495,8 +694,15 @@ class _SpladeEncodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         rt = ctx.rt
+        head = (None, None) + tuple(None for _ in range(ctx.n_in))
+        if ctx.arena is not None:
+            grads = ctx.arena.report(ctx.k, gs[0], ctx.sync_token)
+            ctx.arena = None
+            return head + (tuple(None for _ in rt.params) if grads is None else tuple(grads))
         g_sparse = _gather_rows(gs[:-1], ctx.rows, ctx.vocab, ctx.saved_arena.device)
         grads = rt.backward_impl(ctx.saved_arena, ctx.aux, g_sparse, ctx.sync_token)
+        if ctx.counted:
+            rt.step_arena_backward_done()
         ctx.saved_arena = None
         head = (None, None) + tuple(None for _ in range(ctx.n_in))
         if grads is None:

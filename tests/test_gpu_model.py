@@ -416,6 +416,85 @@ def test_forward_many_equals_separate_passes(dev):
         assert cos > 0.99999 and rel < 2e-3, (n1, cos, rel)      # three launches + accumulate vs one: another fp32 summation tree
 
 
+def _three_call_step(model, pairs, weights, used=(0, 1, 2)):
+    """The reference's call pattern (ref:train_v33_ddp.py:339-343,364): three model(...) calls, one backward."""
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        outs = [model(i, m) for i, m in pairs]
+    sum((outs[j][0] * weights[j]).sum() for j in used).backward()
+    return [(o[0].detach().clone(), o[1].detach().clone()) for o in outs]
+
+
+def test_micro_step_arena_equals_the_fused_pass_bit_for_bit(dev):
+    """snx.encoder.StepArena: from the second micro-step on the unchanged three-call loop fills ONE arena (a pass = the
+    same kernels on a row range: snx_model_forward_range) and its three autograd nodes share ONE deferred native backward.
+    Outputs must equal the stand-alone passes bit for bit; the accumulated gradients must equal those of the explicitly
+    fused pass (forward_many) bit for bit -- same arena contents, same launches, ordered reductions; against three
+    independent backwards only the fp32 summation tree differs (gross-error screen).  Then the fallbacks: a call that
+    breaks the pattern (prefix backward over the passes placed so far) and an output left out of the loss (flat-gradient
+    mode: the engine's end-of-backward callback back-propagates the rest)."""
+    from oracle import splade_oracle as O
+    cfg = _small_cfg()
+    params = O.perturb_params(O.init_params(cfg, seed=3), seed=4, scale=2.0, bias_mean=-0.1)
+    gen = torch.Generator().manual_seed(57)
+    steps = []
+    for _ in range(4):
+        b = O.synth_batch(6, 24, 150, cfg, gen, k=1, ragged=True)
+        steps.append([(b[t + "_input_ids"].to(dev), b[t + "_attention_mask"].to(dev)) for t in ("query", "positive", "negative")])
+    w = [torch.randn(6, cfg.vocab_size, generator=torch.Generator().manual_seed(i), device="cpu").to(dev) for i in range(3)]
+    m_sep, m_arena, m_fused = (_build_model(cfg, params, dev) for _ in range(3))
+    m_sep.runtime.step_arena_on = False
+    assert m_arena.runtime.step_arena_on
+    for it, pairs in enumerate(steps[:3]):
+        o_sep = _three_call_step(m_sep, pairs, w)
+        o_arena = _three_call_step(m_arena, pairs, w)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            many = m_fused.forward_many(pairs)
+        sum((many[j][0] * w[j]).sum() for j in range(3)).backward()
+        assert (m_arena.runtime._pattern is not None) and len(m_arena.runtime._pattern) == 3
+        for (s1, t1), (s2, t2), (s3, t3) in zip(o_sep, o_arena, many):
+            assert torch.equal(s1, s2) and torch.equal(t1, t2) and torch.equal(s2, s3) and torch.equal(t2, t3), it
+    # micro-step 0 ran on the ordinary path in both; 1 and 2 went through the arena: accumulated gradients
+    g_sep = {n: p.grad.clone() for n, p in m_sep.named_parameters()}
+    g_arena = {n: p.grad.clone() for n, p in m_arena.named_parameters()}
+    g_fused = {n: p.grad.clone() for n, p in m_fused.named_parameters()}
+    m_chk = _build_model(cfg, params, dev)                   # micro-step 0 as three passes, 1 and 2 fused: the arena's sum
+    m_chk.runtime.step_arena_on = False
+    _three_call_step(m_chk, steps[0], w)
+    for pairs in steps[1:3]:
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            many = m_chk.forward_many(pairs)
+        sum((many[j][0] * w[j]).sum() for j in range(3)).backward()
+    for n, p in m_chk.named_parameters():
+        assert torch.equal(p.grad, g_arena[n]), (n, float((p.grad - g_arena[n]).abs().max()))
+    for n in g_sep:
+        cos, rel = _grad_stats(g_arena[n], g_sep[n])
+        assert cos > 0.99999 and rel < 2e-3, (n, cos, rel)
+        cos, rel = _grad_stats(g_arena[n], g_fused[n])
+        assert cos > 0.99999 and rel < 2e-3, (n, cos, rel)
+    # ---- a call that breaks the pattern: (q, p) placed, then another shape -> prefix backward + ordinary pass
+    for m in (m_sep, m_arena):
+        m.zero_grad(set_to_none=True)
+    odd = (steps[3][2][0][:, :100].contiguous(), steps[3][2][1][:, :100].contiguous())
+    broken = [steps[3][0], steps[3][1], odd]
+    o_sep = _three_call_step(m_sep, broken, w)
+    o_arena = _three_call_step(m_arena, broken, w)
+    assert m_arena.runtime._pattern is None                  # learnt anew from here
+    for (s1, t1), (s2, t2) in zip(o_sep, o_arena):
+        assert torch.equal(s1, s2) and torch.equal(t1, t2)
+    for (n, p1), (_, p2) in zip(m_sep.named_parameters(), m_arena.named_parameters()):
+        cos, rel = _grad_stats(p2.grad, p1.grad)
+        assert cos > 0.99999 and rel < 2e-3, (n, cos, rel)
+    # ---- an output left out of the loss, in the flat-gradient mode (NativeDataParallel's)
+    from src.train.core import ddp_trainer as T
+    w_sep, w_arena = T.NativeDataParallel(_build_model(cfg, params, dev)), T.NativeDataParallel(_build_model(cfg, params, dev))
+    w_sep.module.runtime.step_arena_on = False
+    for pairs, used in ((steps[0], (0, 1, 2)), (steps[1], (0, 2)), (steps[2], (0, 1, 2))):
+        _three_call_step(w_sep, pairs, w, used)
+        _three_call_step(w_arena, pairs, w, used)
+    fa, fb = w_sep.module.runtime.flat_grad, w_arena.module.runtime.flat_grad
+    assert float((fa - fb).double().norm()) <= 2e-3 * float(fa.double().norm())
+
+
 def test_residual_add_in_the_layernorm_equals_the_gemm_epilogue(dev):
     """snx_configure "resid_in_ln": the Wo GEMMs store bf16 and the following LayerNorm adds it to the fp32 stream
     (snx_ln_fwd_add) instead of the GEMM's residual epilogue -- h + float(bf16(A W^T)) either way: identical outputs, and
@@ -563,6 +642,14 @@ def train_epoch_case(dev, mode):
             captured.append(rt.routing_rows(out[2], out[3]).cpu())
         return out
     rt.forward_many_impl = capturing
+    place = rt.step_arena_place
+
+    def capturing_place(ids, mask):                     # ... and of every pass placed into a micro-step arena
+        out = place(ids, mask)
+        if out is not None:
+            captured.append(out[2].routing_rows(out[3]).cpu())
+        return out
+    rt.step_arena_place = capturing_place
     if mode == "native":
         model = T.NativeDataParallel(inner)
     elif mode == "ddp":
