@@ -631,6 +631,10 @@ int snx_launch_nt256(int epi, const void* A, const void* B, int M, int N, int K,
   const int force = SNX_DIAG_CFG(nt256_force, 0);
   const bool dflt = ((epi == EPI_ROPE || epi == EPI_GEGLU_FWD) && N >= 6 * BN) || (epi == EPI_STORE_BF16 && N >= 3 * BN);
   if (on != 2 && !dflt && !((force >> epi) & 1)) return SNX_E_SHAPE;   // on = 2 (snx_nt256_configure): take all
+  // a plain store with less than one round of 256x256 tiles leaves workgroups idle for the whole launch: the 128x128
+  // kernel is faster there (16,384 rows -- a document pass of the three-call loop --, N = 768: 192 tiles, 30.0 against
+  // 25.0 us at K = 768, 75.9 against 66.0 at K = 2304; profiles/r05_experiments.txt section 4)
+  if (on != 2 && epi == EPI_STORE_BF16 && (long)cdiv(M, BM) * cdiv(N, BN) < NWG) return SNX_E_SHAPE;
   if (!on || M < min_m || (N % 64) || (K % 64) || K < 64) return SNX_E_SHAPE;
   if ((long)M * K * 2 >= (1L << 32) || (long)N * K * 2 >= (1L << 32)) return SNX_E_SHAPE;
   switch (epi) {
