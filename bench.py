@@ -397,8 +397,10 @@ def main():
                            "steps": ksync,
                            "note": "the reference's call pattern unchanged (ref:train_v33_ddp.py:339-343,444): three "
                                    "separate forwards per micro-step (SNX_FUSED_PASSES=0) and loss.item() after "
-                                   "every backward; `value` above runs the three batches as one native pass and "
-                                   "keeps the loss on the device"}
+                                   "every backward -- the three calls fill one micro-step arena and share one deferred "
+                                   "backward (snx.encoder.StepArena; SNX_STEP_ARENA=0: three independent passes, "
+                                   "1,145 triplets/s in round 5); `value` above runs the three batches as one native "
+                                   "pass and keeps the loss on the device"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
