@@ -224,7 +224,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
       if ((hold >> ph) & 1) {
         if (EPI == EPI_GEGLU_FWD) WAIT_VM(28);
         else if (EPI == EPI_RESID_F32 || EPI == EPI_GEGLU_BWD) WAIT_VM(36);
-        else if (EPI == EPI_ROPE && pend == 32) WAIT_VM(36);
         else WAIT_VM(20);
       } else {
 #if defined(SNX_NT256_LEAD_DIAG) && SNX_NT256_LEAD_DIAG == 1   // diagnostics builds: the steady-state wait one / two chunks
@@ -376,13 +375,18 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
     // the staging image; its (cos, sin) are 32 contiguous bytes of the table row, 256 B per row over the 8 lanes
     // (in the accumulator layout the same values were 16 rows x 64 B per load instruction: +33 us per launch).
     // the positions of a pass's rows are loaded TWO passes ahead, its table rows one pass ahead
-    int prow[4][4];
+    // round 5: SIXTEEN-byte pieces -- lane (row = lane >> 2 of 16, q = lane & 3) rotates the EIGHT pairs d = 8 q + 0..7 of
+    // its row: two 16-byte reads of the image, two 16-byte stores, i.e. the store-instruction count of a plain store (the
+    // write-back is bound by the number of vector-memory instructions: with 8-byte pieces the rotated spans cost 32
+    // stores per wave and tile instead of 16, +17 us per launch)
+    const int xr = lane >> 2, xq = lane & 3;
+    int prow[4][2];
     const bool by_row = EPI == EPI_ROPE && e.rope_rows != nullptr;   // (cos, sin) rows resolved per token beforehand
     auto request_pos = [&](int p) __attribute__((always_inline)) {
       if (EPI == EPI_ROPE && rotate && !by_row) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int row = row0 + 32 * p + rr + 8 * k;
+        for (int k = 0; k < 2; ++k) {
+          const int row = row0 + 32 * p + xr + 16 * k;
           prow[p][k] = e.pos[row < M ? row : M - 1];
         }
       }
@@ -393,13 +397,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
       if (EPI == EPI_ROPE) {
         if (rotate) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            int row = row0 + 32 * p + rr + 8 * k;
+          for (int k = 0; k < 2; ++k) {
+            int row = row0 + 32 * p + xr + 16 * k;
             row = row < M ? row : M - 1;
             const f32x2* trow = by_row ? e.rope_rows + (long)row * 32 : e.rope_tab + (long)prow[p][k] * 32;
-            const f32x4* cs = (const f32x4*)(trow + (rc & 3) * 8 + (rc >> 2) * 4);
-            pre[p & 1][2 * k] = cs[0];                       // (cos, sin) of pairs d, d + 1
-            pre[p & 1][2 * k + 1] = cs[1];                   // d + 2, d + 3
+            const f32x4* cs = (const f32x4*)(trow + xq * 8);
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) pre[p & 1][4 * k + c4] = cs[c4];   // (cos, sin) of pairs 8 q + 2 c4, + 1
           }
         }
       } else if (PRE) {
@@ -433,19 +437,19 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
     // Software pipeline over the ONE image: the row-major reads of pass p are issued, then the image is refilled
     // with pass p + 1 (LDS executes a wave's instructions in order: the refill cannot overtake the reads), then the
     // reads are consumed -- their latency runs under the packing and the writes of the next pass.
-    const int d = (rc & 3) * 8 + (rc >> 2) * 4;             // RoPE: this lane's four rotation pairs
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       if (p >= t.u) break;                                  // wave-uniform: a short tile has u passes
       if (p + 2 < 4 && p + 2 < t.u) request_pos(p + 2);
       if (PRE && p + 1 < 4 && p + 1 < t.u) request(p + 1);
       bf16x8 v[4];
-      bf16x4 x1[4], x2[4];
+      bf16x8 x1[2], x2[2];
       if (EPI == EPI_ROPE && rotate) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {                       // the Linear's output is bf16: rotate what was rounded
-          x1[k] = stg_get4(bounce, rr + 8 * k, d);
-          x2[k] = stg_get4(bounce, rr + 8 * k, 32 + d);
+        for (int k = 0; k < 2; ++k) {                       // the Linear's output is bf16: rotate what was rounded
+          // rows xr + 16 k: bit 3 of the row (the image's half swap) is bit 3 of xr for both k
+          x1[k] = (xr & 8) ? stg_get<true>(bounce, xr + 16 * k, xq) : stg_get<false>(bounce, xr + 16 * k, xq);
+          x2[k] = (xr & 8) ? stg_get<true>(bounce, xr + 16 * k, 4 + xq) : stg_get<false>(bounce, xr + 16 * k, 4 + xq);
         }
       } else {
 #pragma unroll
@@ -455,21 +459,21 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
       if (p + 1 < 4 && p + 1 < t.u) put(p + 1);
       if (EPI == EPI_ROPE && rotate) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int row = row0 + 32 * p + rr + 8 * k;
-          const f32x4 q0 = pre[p & 1][2 * k], q1 = pre[p & 1][2 * k + 1];
-          f32x4 lo, hi;
+        for (int k = 0; k < 2; ++k) {
+          const int row = row0 + 32 * p + xr + 16 * k;
+          bf16x8 lo, hi;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float c = (r < 2 ? q0 : q1)[(r & 1) * 2], sn = (r < 2 ? q0 : q1)[(r & 1) * 2 + 1];
+          for (int r = 0; r < 8; ++r) {
+            const f32x4 cs = pre[p & 1][4 * k + (r >> 1)];
+            const float c = cs[(r & 1) * 2], sn = cs[(r & 1) * 2 + 1];
             const float a1 = bf2f(x1[k][r]), a2 = bf2f(x2[k][r]);
-            lo[r] = mul_rn(a1, c) - mul_rn(a2, sn);   // products rounded separately, as torch's
-            hi[r] = mul_rn(a2, c) + mul_rn(a1, sn);   // q * cos + rotate_half(q) * sin (hf:196-219)
+            lo[r] = f2bf(mul_rn(a1, c) - mul_rn(a2, sn));   // products rounded separately, as torch's
+            hi[r] = f2bf(mul_rn(a2, c) + mul_rn(a1, sn));   // q * cos + rotate_half(q) * sin (hf:196-219)
           }
           if (row >= M) continue;
-          bf16_t* o = e.C + (long)row * N + col0 + d;
-          NT256_STORE(bf16x4, o, pack4(lo));
-          NT256_STORE(bf16x4, o + 32, pack4(hi));
+          bf16_t* o = e.C + (long)row * N + col0 + xq * 8;
+          NT256_STORE(bf16x8, o, lo);
+          NT256_STORE(bf16x8, o + 32, hi);
         }
         continue;
       }
@@ -556,7 +560,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
       pend = 16;
       if (EPI == EPI_RESID_F32 || EPI == EPI_GEGLU_BWD) pend = 32;
       if (EPI == EPI_GEGLU_FWD) pend = 24;
-      if (EPI == EPI_ROPE && cur.n0 + wn * 64 < e.rope_cols) pend = 32;
       if (wk.dbg & 8) pend = 0;
     }
     cur = nxt;

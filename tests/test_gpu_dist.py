@@ -195,8 +195,9 @@ def test_three_backward_micro_step_exchanges_once_after_the_last_backward(dev, n
 
 @pytest.mark.parametrize("mode,reserved", [("allreduce", 0), ("rs_ag", 0), ("allreduce", 32)])
 def test_overlapped_exchange_beside_the_persistent_kernels_through_rccl(dev, nccl_world1, monkeypatch, mode, reserved):
-    """One accumulation window of a geometry whose backward runs on the PERSISTENT kernels (256x256 weight-gradient and
-    NT GEMMs, 256x192 decoder: thresholds lowered through snx_configure so that 2,176 token rows qualify), with the
+    """One accumulation window of a geometry whose backward runs on the PERSISTENT kernels (256x256 weight-gradient GEMM,
+    the 256x256 NT kernel for the wide fused Linears, 256x192 decoder: thresholds lowered through snx_configure so that
+    2,176 token rows qualify), with the
     gradient exchange overlapped with the last backward -- buckets through RCCL on the exchange stream while those
     whole-CU kernels are in flight -- against the un-overlapped path (no buckets: one all-reduce of the whole buffer
     after the backward).  At world size 1 every collective is the identity and the weight gradients are reduced in a
