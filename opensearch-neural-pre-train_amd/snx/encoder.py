@@ -466,14 +466,17 @@ class EncoderRuntime:
             self._pattern = None
             return None
         k = 0 if a is None else a.placed
-        if self._open_nodes or k >= len(self._pattern) or shape != self._pattern[k]:
+        # the FIRST pass of a micro-step may have any shape (the arena is laid out when it arrives): with the reference's
+        # collator (padding to the longest of the batch, ref:src/train/data/dataloader.py:95-118) the query length changes
+        # from batch to batch while the documents sit at max_length; later passes must match the prediction
+        if self._open_nodes or k >= len(self._pattern) or (k > 0 and shape != a.pattern[k]):
             if a is not None:
                 a.broken = True                              # the passes placed so far back-propagate as a prefix
                 self._arena = None
             self._pattern = None
             return None
         if a is None:
-            a = self._arena = StepArena(self, self._pattern)
+            a = self._arena = StepArena(self, (shape,) + tuple(self._pattern[1:]))
         return a.place(ids, mask)
 
     def __call__(self, input_ids, attention_mask):

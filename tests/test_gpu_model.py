@@ -471,6 +471,20 @@ def test_micro_step_arena_equals_the_fused_pass_bit_for_bit(dev):
         assert cos > 0.99999 and rel < 2e-3, (n, cos, rel)
         cos, rel = _grad_stats(g_arena[n], g_fused[n])
         assert cos > 0.99999 and rel < 2e-3, (n, cos, rel)
+    # ---- the first pass of a micro-step may change its length (dynamic padding of the queries): still one arena
+    for m in (m_arena, m_chk):
+        m.zero_grad(set_to_none=True)
+    short_q = (steps[3][0][0][:, :16].contiguous(), steps[3][0][1][:, :16].contiguous())
+    varied = [short_q, steps[3][1], steps[3][2]]
+    _three_call_step(m_arena, varied, w)
+    assert m_arena.runtime._pattern is not None and m_arena.runtime._pattern[0] == (6, 16)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        many = m_chk.forward_many(varied)
+    sum((many[j][0] * w[j]).sum() for j in range(3)).backward()
+    for (n, p1), (_, p2) in zip(m_chk.named_parameters(), m_arena.named_parameters()):
+        assert torch.equal(p1.grad, p2.grad), n
+    _three_call_step(m_arena, steps[2], w)                   # ... and back to the long queries: the pattern is alive again
+    assert m_arena.runtime._pattern is not None and m_arena.runtime._pattern[0] == (6, 24)
     # ---- a call that breaks the pattern: (q, p) placed, then another shape -> prefix backward + ordinary pass
     for m in (m_sep, m_arena):
         m.zero_grad(set_to_none=True)
