@@ -40,6 +40,9 @@ GUARDED: Dict[str, Tuple[str, ...]] = {
 # helper-wave form loads through plain C++ again and passes trivially, with zero scratch.
 VM_GUARDED: Dict[str, Tuple[str, ...]] = {
     "gemm_nt_pipe.hip": ("gemm_nt_geglu_bwd_pipe_kernel",),
+    # the resident attention forward requests its key mask through asm volatile("global_load_dwordx2") and waits for it
+    # with an asm s_waitcnt vmcnt(0) further down (round-4 advisor finding: nothing protected other flag sets)
+    "attention_unit.hip": ("attn_fwd_unit_kernel",),
 }
 
 _REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
