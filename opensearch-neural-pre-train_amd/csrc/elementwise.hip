@@ -445,35 +445,37 @@ __global__ void embed_count_kernel(const int64_t* __restrict__ ids, int* __restr
   const long id = ids[t];
   if (id != pad_id && id >= 0 && id < V) atomicAdd(cnt + id, 1);
 }
-// off[v] = sum of cnt[0..v), off[V] = total.  One workgroup walks the ids in chunks of 1024 with coalesced loads: wave-level
-// inclusive scan (6 shuffles), the 16 wave totals scanned by every thread from LDS, a running offset carried from chunk to
-// chunk (the first form gave each thread a contiguous run of 49 ids: 196-byte strides, 75 us for 50,000 ids).
+// off[v] = sum of cnt[0..v), off[V] = total.  One workgroup per chunk of 1024 ids: it sums everything in front of its
+// chunk by itself (coalesced, at most V loads per workgroup: 50,000 ids = 49 workgroups, 1.2 M loads in all -- no second
+// pass, no inter-workgroup dependency), then scans its chunk (wave-level shuffles + the 16 wave totals through LDS).
+// (One workgroup walking all chunks took 45 us, a contiguous run of ids per thread 75 us.)
 __global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int V) {
-  __shared__ int wsum[2][16];
+  __shared__ int wsum[16], wpre[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int run = 0;
-  for (int v0 = 0, it = 0; v0 < V; v0 += 1024, ++it) {
-    const int v = v0 + threadIdx.x;
-    const int c = v < V ? cnt[v] : 0;
-    int inc = c;
+  const int v0 = blockIdx.x * 1024;
+  int before = 0;
+  for (int v = threadIdx.x; v < v0; v += 1024) before += cnt[v];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int up = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += up;
-    }
-    if (lane == 63) wsum[it & 1][wave] = inc;
-    __syncthreads();                                   // (two buffers: the next chunk's writes cannot overtake these reads)
-    int before = 0, total = 0;
+  for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+  if (lane == 0) wpre[wave] = before;
+  const int v = v0 + threadIdx.x;
+  const int c = v < V ? cnt[v] : 0;
+  int inc = c;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      const int t = wsum[it & 1][w];
-      if (w < wave) before += t;
-      total += t;
-    }
-    if (v < V) off[v] = run + before + inc - c;
-    run += total;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += up;
   }
-  if (threadIdx.x == 0) off[V] = run;
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    base += wpre[w];
+    if (w < wave) base += wsum[w];
+  }
+  if (v < V) off[v] = base + inc - c;
+  if (v == V - 1) off[V] = base + inc;
 }
 __global__ void embed_fill_kernel(const int64_t* __restrict__ ids, const int* __restrict__ off, int* __restrict__ fill,
                                   int* __restrict__ list, int T, int V, int pad_id) {
@@ -603,7 +605,7 @@ int snx_embed_ln_bwd_x(const float* dh, const int64_t* ids, const float* E, cons
     cnt = (int*)(base + o); fill = cnt + V; off = fill + V; list = off + V + 1; sorted = list + T;
     if (hipMemsetAsync(cnt, 0, (size_t)2 * V * 4, st) != hipSuccess) return SNX_E_ARG;
     hipLaunchKernelGGL(embed_count_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, ids, cnt, T, V, pad_id);
-    hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)cnt, off, V);
+    hipLaunchKernelGGL(embed_scan_kernel, dim3(cdiv(V, 1024)), dim3(1024), 0, st, (const int*)cnt, off, V);
     hipLaunchKernelGGL(embed_fill_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, ids, (const int*)off, fill, list, T, V, pad_id);
     hipLaunchKernelGGL(embed_rank_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, ids, (const int*)off, (const int*)list,
                        sorted, T, V, pad_id);

@@ -84,6 +84,19 @@ def test_shape_validation_happens_on_the_host():
     for ub, ue, want in ((0, L + 3, -3), (-1, 2, -3), (3, 3, -3), (5, 2, -3)):
         assert fn("snx_model_backward_units")(C.byref(d), *nine[:12], None, 64, 1, 64, ub, ue, None, None) == want, (ub, ue)
     assert fn("snx_model_backward_units")(C.byref(d), None, *nine[:11], None, 64, 1, 64, 0, L + 2, None, None) == -3
+    # a pass of a micro-step arena: the row / sequence range must lie inside the plan, a true sub-range takes no groups and
+    # must save for backward (host checks, no launch)
+    fr = fn("snx_model_forward_range")
+    ptrs = [one] * 11
+    for tp, npl, r0, s0, t, ns, flags, want in ((576, 3, 512, 2, 128, 1, 1, -3),     # rows past the plan
+                                                (576, 3, 0, 3, 64, 1, 1, -3),         # sequences past the plan
+                                                (576, 3, -1, 0, 64, 1, 1, -3),
+                                                (576, 3, 64, 1, 256, 1, 0, -3)):      # sub-range without save
+        assert fr(C.byref(d), *ptrs, None, tp, npl, r0, s0, t, ns, 256, flags, None) == want, (tp, npl, r0, s0, t, ns)
+    grp = (C.c_int32 * 4)(1, 0, 1, 64)
+    assert fr(C.byref(d), *ptrs, grp, 576, 3, 64, 1, 256, 1, 256, 1, None) == -3     # groups on a sub-range
+    br = fn("snx_model_backward_units_range")
+    assert br(C.byref(d), *nine[:12], None, 64, 1, 128, 1, 64, 0, L + 2, None, None) == -3   # more rows than planned
 
 
 def test_product_path_has_no_cpu_fallback():
