@@ -360,3 +360,54 @@ def test_bench_shape_micro_step_against_the_oracle(dev, full):
     for k in grads:
         assert torch.equal(grads[k], grads0[k]), (k, float((grads[k] - grads0[k]).abs().max()))
     model.zero_grad(set_to_none=True)
+
+
+def test_unchanged_three_call_loop_at_the_bench_shape_equals_the_fused_pass(dev, full):
+    """The reference's literal micro-step (three model(...) calls, one loss, one backward: ref:train_v33_ddp.py:339-364) at
+    the bench's shape, 149 M parameters: the first micro-step teaches the runtime the pattern, the second runs through the
+    micro-step arena (snx.encoder.StepArena: every call fills its 4,096 / 16,384 rows of ONE 36,864-row arena, ONE deferred
+    backward on the full-size launches).  Outputs, loss and all 137 gradient tensors of that second micro-step must equal the
+    explicitly fused pass bit for bit."""
+    from src.model.losses import SPLADELossV33
+    cfg, params, model = full
+    rt = model.runtime
+    keep, rt.keep_last_ctx = rt.keep_last_ctx, False          # (the parity instrumentation pins per-pass arenas)
+    gen = torch.Generator().manual_seed(2027)
+    B, Sq, Sd = 64, 64, 256
+
+    def ids(S):
+        x = torch.randint(6, cfg.pad_token_id, (B, S), generator=gen)
+        x[:, 0] = 0
+        x[:, -1] = 1
+        return x.to(dev)
+    batches = [(ids(Sq), ids(Sd), ids(Sd)) for _ in range(2)]
+    lf = SPLADELossV33(temperature=500.0).to(dev)
+    try:
+        def three_call(q, p, n):
+            model.zero_grad(set_to_none=True)
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                a, _ = model(q, torch.ones_like(q))
+                pp, _ = model(p, torch.ones_like(p))
+                nn_, _ = model(n, torch.ones_like(n))
+                loss, _ = lf(anchor_repr=a, positive_repr=pp, negative_repr=nn_, global_step=50)
+            loss.backward()
+            return a.detach(), pp.detach(), nn_.detach(), float(loss), {k: v.grad.detach().clone() for k, v in model.named_parameters()}
+
+        rt._pattern, rt._observed, rt._open_nodes, rt._arena = None, [], 0, None
+        three_call(*batches[0])                               # ordinary path: learns (64, 64), (64, 256), (64, 256)
+        assert rt._pattern == ((B, Sq), (B, Sd), (B, Sd))
+        a, pp, nn_, loss, grads = three_call(*batches[1])     # through the arena
+        assert rt._pattern == ((B, Sq), (B, Sd), (B, Sd)) and rt._arena is None
+        model.zero_grad(set_to_none=True)
+        q, p, n = batches[1]
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            (a2, _), (p2, _), (n2, _) = model.forward_many([(q, torch.ones_like(q)), (p, torch.ones_like(p)), (n, torch.ones_like(n))])
+            loss2, _ = lf(anchor_repr=a2, positive_repr=p2, negative_repr=n2, global_step=50)
+        loss2.backward()
+        assert torch.equal(a, a2) and torch.equal(pp, p2) and torch.equal(nn_, n2) and loss == float(loss2)
+        for k, v in model.named_parameters():
+            assert torch.equal(v.grad, grads[k]), (k, float((v.grad - grads[k]).abs().max()))
+    finally:
+        rt.keep_last_ctx = keep
+        rt._pattern, rt._observed, rt._open_nodes, rt._arena = None, [], 0, None
+        model.zero_grad(set_to_none=True)
