@@ -409,9 +409,10 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
 }
 
 // ---- ordered reduction of the partial slabs -------------------------------------------------------------------------
-// dW tile += slab(0) + slab(1) + ... in contributor order (see contributor_of).  One workgroup per (tile, 32-row
-// chunk); a thread owns 4 consecutive k of 8 rows: every access is a whole 16-byte piece of a 1-KiB row.  The slabs were
-// written a moment ago by the GEMM kernel (the group's 60-100 MB sit in the 256-MiB Infinity Cache).
+// dW tile += slab(0) + slab(1) + ... in contributor order (see contributor_of).  One workgroup per (tile, 16-row
+// chunk); a thread owns 4 consecutive k of 4 rows: every access is a whole 16-byte piece of a 1-KiB row.  The slabs were
+// written a moment ago by the GEMM kernel (the group's 60-100 MB sit in the 256-MiB Infinity Cache).  (32-row chunks:
+// 624 workgroups for the layer group = 2.4 per CU, three rounds of ~10 us; 16-row chunks: 1,248.)
 __global__ __launch_bounds__(256) void tn256_reduce_kernel(TnGroup grp, Sched sch) {
   const int tile = blockIdx.x, chunk = blockIdx.y;
   const Tile t = decode(grp, tile);
@@ -421,8 +422,8 @@ __global__ __launch_bounds__(256) void tn256_reduce_kernel(TnGroup grp, Sched sc
   const int ntail = tail_contributors(sch, tile);
   const size_t tile_stride = (size_t)sch.ntiles * (256 * 256);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int nl = chunk * 32 + q * 4 + (threadIdx.x >> 6);
+  for (int q = 0; q < 4; ++q) {
+    const int nl = chunk * 16 + q * 4 + (threadIdx.x >> 6);
     int n = t.n0 + nl;
     if (n >= t.N) continue;
     if (t.inter > 0) n = ((n & 63) < 32) ? 32 * (n >> 6) + (n & 31) : t.inter + 32 * (n >> 6) + (n & 31);
@@ -521,7 +522,7 @@ int snx_launch_tn256(const TnGroup& g128, int M, void* ws, size_t ws_bytes, hipS
   hipLaunchKernelGGL(kern, dim3(NWG), dim3(256), RING * SLOT, st, g, M, s);
   SNX_CHECK_LAUNCH();
   if (s.ws && !(dbg & 1)) {
-    hipLaunchKernelGGL(tn256_reduce_kernel, dim3(s.ntiles, 8), dim3(256), 0, st, g, s);
+    hipLaunchKernelGGL(tn256_reduce_kernel, dim3(s.ntiles, 16), dim3(256), 0, st, g, s);
     SNX_CHECK_LAUNCH();
   }
   return SNX_OK;
