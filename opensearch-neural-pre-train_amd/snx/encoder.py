@@ -100,12 +100,12 @@ class EncoderRuntime:
         self.last_ctx = None
         # bucketed gradient exchange overlapped with the backward (snx.dist.BucketedGradSync); armed per call
         self.grad_sync = None
-        # micro-step arena (StepArena below): the call pattern learnt from the previous micro-step, the shapes seen since the
-        # last completed backward, saving forwards not yet back-propagated, the arena being filled
+        # micro-step arena (StepArena below): rows / sequences / passes of the micro-step in progress, the capacity learnt from
+        # the recent micro-steps (their maxima), the arena being filled
         self.step_arena_on = os.environ.get("SNX_STEP_ARENA", "1") != "0"
-        self._pattern: Optional[tuple] = None
-        self._observed: list = []
-        self._open_nodes = 0
+        self._step_phase = "bwd"                             # "fwd": forwards of a micro-step are arriving
+        self._step_tot = [0, 0, 0]                           # token rows, sequences, passes of the micro-step in progress
+        self._step_hist: list = []                           # totals of the last micro-steps
         self._arena: Optional["StepArena"] = None
 
     # ------------------------------------------------------------------ parameter plumbing
@@ -437,46 +437,54 @@ class EncoderRuntime:
         return (self.step_arena_on and not self.keep_last_ctx and self.precision() == "bf16" and
                 self.geom.bf16_unsupported_reason() is None)
 
+    def step_arena_capacity(self):
+        """(token rows, sequences) an arena is laid out for: the maxima of the last micro-steps (dynamic padding makes
+        them fluctuate), or None while no micro-step with at least two passes has been seen."""
+        h = [t for t in self._step_hist if t[2] >= 2]
+        if not h:
+            return None
+        return max(t[0] for t in h), max(t[1] for t in h)
+
+    def _step_forward(self, ids: torch.Tensor) -> None:
+        if self._step_phase == "bwd":                        # first forward after a backward: a new micro-step begins
+            self._step_phase, self._step_tot = "fwd", [0, 0, 0]
+        self._step_tot[0] += int(ids.shape[0]) * int(ids.shape[1])
+        self._step_tot[1] += int(ids.shape[0])
+        self._step_tot[2] += 1
+
+    def step_arena_backward_begins(self) -> None:
+        """Any backward of a saving single-batch forward: the micro-step's forwards are complete."""
+        if self._step_phase == "fwd":
+            self._step_phase = "bwd"
+            if 2 <= self._step_tot[2] <= StepArena.MAX_PASSES:   # (a run of forwards that is no micro-step teaches nothing)
+                self._step_hist = (self._step_hist + [tuple(self._step_tot)])[-8:]
+
     def step_arena_observe(self, ids: torch.Tensor) -> bool:
-        """A single-batch saving forward on the ordinary path: part of the pattern being learnt.  True: its backward
-        reports back (step_arena_backward_done)."""
+        """A single-batch saving forward on the ordinary path.  True: its backward reports back."""
         if not self._arena_eligible():
-            self._pattern, self._observed, self._open_nodes = None, [], 0
+            self._step_hist, self._step_phase = [], "bwd"
             return False
-        self._observed.append((int(ids.shape[0]), int(ids.shape[1])))
-        self._open_nodes += 1
+        self._step_forward(ids)
         return True
 
-    def step_arena_backward_done(self) -> None:
-        self._open_nodes -= 1
-        if self._open_nodes == 0:
-            # every forward made since the last completed backward has been back-propagated: that was one micro-step
-            self._pattern = tuple(self._observed) if 2 <= len(self._observed) <= 8 else None
-            self._observed = []
-
     def step_arena_place(self, ids: torch.Tensor, mask: torch.Tensor):
-        """The next pass of the learnt pattern -> (sparse [B, V], token_weights [B*S], arena, index), or None when this call
-        does not continue the pattern (then it runs on the ordinary path and the pattern is learnt anew)."""
-        if self._pattern is None or not self._arena_eligible() or ids.dim() != 2 or mask.shape != ids.shape or \
-                ids.device != self._device() or mask.device != ids.device:
+        """This pass into the micro-step's shared arena -> (sparse [B, V], token_weights [B*S], arena, index), or None when
+        no capacity has been learnt yet or the pass does not fit what is left of it (then it runs on the ordinary path)."""
+        if not self._arena_eligible() or ids.dim() != 2 or mask.shape != ids.shape or ids.device != self._device() or \
+                mask.device != ids.device:
+            return None
+        cap = self.step_arena_capacity()
+        if cap is None:
             return None
         a = self._arena
-        shape = (int(ids.shape[0]), int(ids.shape[1]))
-        if a is not None and a.closed:                       # backwards of the previous micro-step still outstanding
-            self._pattern = None
-            return None
-        k = 0 if a is None else a.placed
-        # the FIRST pass of a micro-step may have any shape (the arena is laid out when it arrives): with the reference's
-        # collator (padding to the longest of the batch, ref:src/train/data/dataloader.py:95-118) the query length changes
-        # from batch to batch while the documents sit at max_length; later passes must match the prediction
-        if self._open_nodes or k >= len(self._pattern) or (k > 0 and shape != a.pattern[k]):
-            if a is not None:
-                a.broken = True                              # the passes placed so far back-propagate as a prefix
-                self._arena = None
-            self._pattern = None
-            return None
+        B, S = int(ids.shape[0]), int(ids.shape[1])
         if a is None:
-            a = self._arena = StepArena(self, (shape,) + tuple(self._pattern[1:]))
+            if B * S > cap[0] or B > cap[1]:
+                return None
+            a = self._arena = StepArena(self, cap[0], cap[1])
+        if not a.fits(B, S):
+            return None
+        self._step_forward(ids)
         return a.place(ids, mask)
 
     def __call__(self, input_ids, attention_mask):
@@ -514,27 +522,27 @@ class StepArena:
     ref:src/train/cli/train_v33_ddp.py:339-343) and back-propagates once (:364).  Run as three independent passes that costs
     10 ms per micro-step of DEVICE time over the fused pass (402 + 69 GEMM launches of a third of the rows each:
     profiles/r05_caller_breakdown.txt), two thirds of it in the backward.  Without touching the caller: the runtime learns
-    the sequence of (batch, seq_len) shapes of one micro-step, and in the next one lays the arena out for the whole pattern
-    and lets every model(...) call fill its row range (snx_model_forward_range: the same kernels on shifted pointers, so
-    the outputs are bit-identical to a stand-alone pass).  The backward calls of the three autograd nodes only hand in
-    their output gradients; the LAST one to report runs the fused native backward over the whole arena -- the launches
-    (and the bucketed gradient exchange) of the fused micro-step.  A call that does not continue the pattern falls back to
-    the ordinary path; the passes already placed back-propagate as a prefix of the arena; the pattern is learnt anew.
+    how many token rows and sequences a micro-step holds (the maxima of the last eight: the reference's collator pads to the
+    longest of each batch, ref:src/train/data/dataloader.py:95-118, so they fluctuate), lays an arena out for that capacity
+    and lets every model(...) call fill the next row range (snx_model_forward_range: the same kernels on shifted pointers,
+    outputs bit-identical to a stand-alone pass).  The backward calls of the autograd nodes only hand in their output
+    gradients; the LAST one to report runs the fused native backward over the rows actually filled
+    (snx_model_backward_units_range) -- the launches, and the bucketed gradient exchange, of the fused micro-step, and bit
+    for bit its gradients.  A pass that does not fit what is left of the capacity runs on the ordinary path.
 
-    Limits (documented, checked): bf16 path, dense [B, S] batches (no `lengths`), every placed pass must take part in the
-    loss -- if the autograd engine finishes a backward pass with a placed node unreported, the remaining gradient is
-    back-propagated with zeros for it in the flat-gradient mode and raised as an error otherwise."""
+    Limits (documented, checked): bf16 path, dense [B, S] batches (no `lengths`), at most eight passes, every placed pass
+    must take part in the loss -- if the autograd engine finishes a backward pass with a placed node unreported, the
+    remaining gradient is back-propagated with zeros for it in the flat-gradient mode and raised as an error otherwise."""
 
-    def __init__(self, rt: "EncoderRuntime", pattern):
-        self.rt, self.pattern = rt, tuple(pattern)
+    MAX_PASSES = 8
+
+    def __init__(self, rt: "EncoderRuntime", t_cap: int, nseq_cap: int):
+        self.rt = rt
         dev = rt._device()
         self.dev = dev
+        self.T, self.nseq = int(t_cap), int(nseq_cap)
+        self.shapes: list = []
         self.row0, self.seq0 = [0], [0]
-        for B, S in self.pattern:
-            self.row0.append(self.row0[-1] + B * S)
-            self.seq0.append(self.seq0[-1] + B)
-        self.T, self.nseq = self.row0[-1], self.seq0[-1]
-        self.smax = max(S for _, S in self.pattern)
         V = rt.geom.vocab_size
         with torch.cuda.device(dev):
             nbytes = fn("snx_model_workspace_bytes")(C.byref(rt._desc), self.T, self.nseq, 1)
@@ -544,34 +552,39 @@ class StepArena:
             self.ids = torch.empty((self.T,), dtype=torch.int64, device=dev)
             self.mask = torch.empty((self.T,), dtype=torch.int64, device=dev)
         self.placed = self.reported = 0
-        self.grads = [None] * len(self.pattern)
-        self.closed = self.broken = self.done = False
-        self.last_token = None
+        self.grads: list = []
+        self.closed = self.done = False
+
+    def fits(self, B: int, S: int) -> bool:
+        return (not self.closed and self.placed < self.MAX_PASSES and self.row0[-1] + B * S <= self.T and
+                self.seq0[-1] + B <= self.nseq)
 
     def place(self, ids: torch.Tensor, mask: torch.Tensor):
         rt, k = self.rt, self.placed
-        B, S = self.pattern[k]
-        r0, s0, T = self.row0[k], self.seq0[k], B * S
+        B, S = int(ids.shape[0]), int(ids.shape[1])
+        r0, s0, T = self.row0[-1], self.seq0[-1], B * S
         cu, pos, _ = rt._layout([(B, S)], self.dev)
         ids_k, mask_k = self.ids[r0:r0 + T], self.mask[r0:r0 + T]
         ids_k.copy_(ids.reshape(-1))
         mask_k.copy_(mask.reshape(-1))
         hd = rt.geom.hidden_size // rt.geom.num_attention_heads
         with torch.cuda.device(self.dev):
-            rg, rl = rt._rope_tables(max(self.smax, 64), self.dev, hd)
+            rg, rl = rt._rope_tables(max(S, 64), self.dev, hd)
             check(fn("snx_model_forward_range")(C.byref(rt._desc), rt._param_ptrs(), _p(rt._weights()), _p(ids_k), _p(mask_k),
                                                 _p(cu), _p(pos), _p(rg), _p(rl), _p(self.saved), _p(self.sparse), _p(self.tw),
                                                 None, self.T, self.nseq, r0, s0, T, B, S, SNX_FWD_SAVE_FOR_BACKWARD,
                                                 _stream()), "snx_model_forward_range")
+        self.shapes.append((B, S))
+        self.row0.append(r0 + T)
+        self.seq0.append(s0 + B)
+        self.grads.append(None)
         self.placed += 1
-        if self.placed == len(self.pattern):
-            rt._arena = None                                 # complete: the next forward opens a new micro-step
         return self.sparse[s0:s0 + B], self.tw[r0:r0 + T], self, k
 
     def routing_rows(self, k: int) -> torch.Tensor:
         """Arg-max sequence position per (sequence, vocab) entry of pass k (as EncoderRuntime.routing_rows)."""
         rt, V = self.rt, self.rt.geom.vocab_size
-        B = self.pattern[k][0]
+        B = self.shapes[k][0]
         off = fn("snx_model_keys_offset")(C.byref(rt._desc), self.T, self.nseq) + self.seq0[k] * V * 4
         keys = self.saved[off:off + B * V * 4].view(torch.int32).view(B, -1).to(torch.int64) & 0xFFFFFFFF
         return 0xFFFF - (keys & 0xFFFF)
@@ -584,6 +597,7 @@ class StepArena:
             self.closed = True                               # no further pass can join; the engine tells us when it is done
             if rt._arena is self:
                 rt._arena = None
+            rt.step_arena_backward_begins()
             torch.autograd.Variable._execution_engine.queue_callback(self._engine_done)
         self.grads[k] = g
         self.reported += 1
@@ -597,21 +611,19 @@ class StepArena:
     def _run(self, token):
         rt, n = self.rt, self.placed
         self.done = True
-        shapes = list(self.pattern[:n])
-        T, nseq = self.row0[n], self.seq0[n]
+        shapes = list(self.shapes)
+        T, nseq = self.row0[-1], self.seq0[-1]
         V = rt.geom.vocab_size
         parts = [g.to(torch.float32) if g is not None else torch.zeros((b, V), dtype=torch.float32, device=self.dev)
-                 for g, (b, _) in zip(self.grads[:n], shapes)]
+                 for g, (b, _) in zip(self.grads, shapes)]
         g_all = _gather_rows(parts, [b for b, _ in shapes], V, self.dev)
         cu, pos, groups = rt._layout(shapes, self.dev)
+        smax = max(s for _, s in shapes)
         hd = rt.geom.hidden_size // rt.geom.num_attention_heads
-        rg, rl = rt._rope_tables(max(self.smax, 64), self.dev, hd)
-        aux = (self.ids[:T], self.mask[:T], cu, pos, rg, rl, T, nseq, max(s for _, s in shapes),
-               groups if n > 1 else None, False)
+        rg, rl = rt._rope_tables(max(smax, 64), self.dev, hd)
+        aux = (self.ids[:T], self.mask[:T], cu, pos, rg, rl, T, nseq, smax, groups if n > 1 else None, False)
         grads = rt.backward_impl(self.saved, aux, g_all, token, plan=(self.T, self.nseq))
         self.saved = None
-        if not self.broken and n == len(self.pattern):
-            rt._pattern = self.pattern                       # the pattern held: keep it for the next micro-step
         self.grads = []
         return grads
 
@@ -620,7 +632,6 @@ class StepArena:
         if self.done:
             return
         rt = self.rt
-        rt._pattern = None
         if not rt.direct_grads:
             raise RuntimeError("snx: a model(...) output of this micro-step took no part in the loss, so its backward never "
                                "ran and the deferred backward of the micro-step arena cannot return its gradients through "
@@ -705,7 +716,7 @@ class _SpladeEncodeFn(torch.autograd.Function):
         g_sparse = _gather_rows(gs[:-1], ctx.rows, ctx.vocab, ctx.saved_arena.device)
         grads = rt.backward_impl(ctx.saved_arena, ctx.aux, g_sparse, ctx.sync_token)
         if ctx.counted:
-            rt.step_arena_backward_done()
+            rt.step_arena_backward_begins()
         ctx.saved_arena = None
         head = (None, None) + tuple(None for _ in range(ctx.n_in))
         if grads is None:

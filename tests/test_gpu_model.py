@@ -429,8 +429,9 @@ def test_micro_step_arena_equals_the_fused_pass_bit_for_bit(dev):
     same kernels on a row range: snx_model_forward_range) and its three autograd nodes share ONE deferred native backward.
     Outputs must equal the stand-alone passes bit for bit; the accumulated gradients must equal those of the explicitly
     fused pass (forward_many) bit for bit -- same arena contents, same launches, ordered reductions; against three
-    independent backwards only the fp32 summation tree differs (gross-error screen).  Then the fallbacks: a call that
-    breaks the pattern (prefix backward over the passes placed so far) and an output left out of the loss (flat-gradient
+    independent backwards only the fp32 summation tree differs (gross-error screen).  Then: a first pass of another length
+    (dynamic padding), a pass that no longer fits the capacity (prefix backward over the passes placed so far + ordinary
+    path) and an output left out of the loss (flat-gradient
     mode: the engine's end-of-backward callback back-propagates the rest)."""
     from oracle import splade_oracle as O
     cfg = _small_cfg()
@@ -450,7 +451,7 @@ def test_micro_step_arena_equals_the_fused_pass_bit_for_bit(dev):
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
             many = m_fused.forward_many(pairs)
         sum((many[j][0] * w[j]).sum() for j in range(3)).backward()
-        assert (m_arena.runtime._pattern is not None) and len(m_arena.runtime._pattern) == 3
+        assert m_arena.runtime.step_arena_capacity() == (6 * (24 + 150 + 150), 18)
         for (s1, t1), (s2, t2), (s3, t3) in zip(o_sep, o_arena, many):
             assert torch.equal(s1, s2) and torch.equal(t1, t2) and torch.equal(s2, s3) and torch.equal(t2, t3), it
     # micro-step 0 ran on the ordinary path in both; 1 and 2 went through the arena: accumulated gradients
@@ -477,22 +478,23 @@ def test_micro_step_arena_equals_the_fused_pass_bit_for_bit(dev):
     short_q = (steps[3][0][0][:, :16].contiguous(), steps[3][0][1][:, :16].contiguous())
     varied = [short_q, steps[3][1], steps[3][2]]
     _three_call_step(m_arena, varied, w)
-    assert m_arena.runtime._pattern is not None and m_arena.runtime._pattern[0] == (6, 16)
+    assert m_arena.runtime._step_hist[-1] == (6 * (16 + 150 + 150), 18, 3)          # all three went through the arena
     with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         many = m_chk.forward_many(varied)
     sum((many[j][0] * w[j]).sum() for j in range(3)).backward()
     for (n, p1), (_, p2) in zip(m_chk.named_parameters(), m_arena.named_parameters()):
         assert torch.equal(p1.grad, p2.grad), n
-    _three_call_step(m_arena, steps[2], w)                   # ... and back to the long queries: the pattern is alive again
-    assert m_arena.runtime._pattern is not None and m_arena.runtime._pattern[0] == (6, 24)
-    # ---- a call that breaks the pattern: (q, p) placed, then another shape -> prefix backward + ordinary pass
+    _three_call_step(m_arena, steps[2], w)                   # ... and back to the long queries: the capacity is the maximum
+    assert m_arena.runtime.step_arena_capacity() == (6 * (24 + 150 + 150), 18)
+    # ---- a pass that does not fit what is left of the capacity: (q, p) placed, then twice the rows -> the arena back-propagates
+    # its two passes as a prefix, the third runs on the ordinary path
     for m in (m_sep, m_arena):
         m.zero_grad(set_to_none=True)
-    odd = (steps[3][2][0][:, :100].contiguous(), steps[3][2][1][:, :100].contiguous())
-    broken = [steps[3][0], steps[3][1], odd]
+    big = (torch.cat([steps[3][2][0]] * 2, 1).contiguous(), torch.cat([steps[3][2][1]] * 2, 1).contiguous())   # [6, 300]
+    broken = [steps[3][0], steps[3][1], big]
     o_sep = _three_call_step(m_sep, broken, w)
     o_arena = _three_call_step(m_arena, broken, w)
-    assert m_arena.runtime._pattern is None                  # learnt anew from here
+    assert m_arena.runtime._step_hist[-1] == (6 * (24 + 150 + 300), 18, 3)            # ... and the capacity has grown
     for (s1, t1), (s2, t2) in zip(o_sep, o_arena):
         assert torch.equal(s1, s2) and torch.equal(t1, t2)
     for (n, p1), (_, p2) in zip(m_sep.named_parameters(), m_arena.named_parameters()):

@@ -393,11 +393,11 @@ def test_unchanged_three_call_loop_at_the_bench_shape_equals_the_fused_pass(dev,
             loss.backward()
             return a.detach(), pp.detach(), nn_.detach(), float(loss), {k: v.grad.detach().clone() for k, v in model.named_parameters()}
 
-        rt._pattern, rt._observed, rt._open_nodes, rt._arena = None, [], 0, None
-        three_call(*batches[0])                               # ordinary path: learns (64, 64), (64, 256), (64, 256)
-        assert rt._pattern == ((B, Sq), (B, Sd), (B, Sd))
+        rt._step_hist, rt._step_phase, rt._arena = [], "bwd", None
+        three_call(*batches[0])                               # ordinary path: learns 36,864 rows, 192 sequences, 3 passes
+        assert rt.step_arena_capacity() == (B * (Sq + 2 * Sd), 3 * B)
         a, pp, nn_, loss, grads = three_call(*batches[1])     # through the arena
-        assert rt._pattern == ((B, Sq), (B, Sd), (B, Sd)) and rt._arena is None
+        assert rt._step_hist[-1] == (B * (Sq + 2 * Sd), 3 * B, 3) and rt._arena is None
         model.zero_grad(set_to_none=True)
         q, p, n = batches[1]
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
@@ -409,5 +409,5 @@ def test_unchanged_three_call_loop_at_the_bench_shape_equals_the_fused_pass(dev,
             assert torch.equal(v.grad, grads[k]), (k, float((v.grad - grads[k]).abs().max()))
     finally:
         rt.keep_last_ctx = keep
-        rt._pattern, rt._observed, rt._open_nodes, rt._arena = None, [], 0, None
+        rt._step_hist, rt._step_phase, rt._arena = [], "bwd", None
         model.zero_grad(set_to_none=True)
