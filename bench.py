@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-item-sync-leg", action="store_true",
                     help="skip the extra leg that times the reference's literal loop (three forwards + loss.item())")
+    ap.add_argument("--no-sparse-regime-leg", action="store_true",
+                    help="skip the extra leg that times the step with a trained model's output sparsity")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="time the CPU oracle sample and exit (no GPU)")
     ap.add_argument("--cpu-cores", default=None, help="threads of the CPU sample: a number, or 'all' (physical cores)")
     args = ap.parse_args()
@@ -332,6 +334,29 @@ def main():
         "gflop_per_triplet": {"algorithmic_3x_fwd": fl["step"] / 1e9, "executed_sparse_decoder_bwd": fl["step_executed"] / 1e9},
     }
 
+    # ---- what the communicator itself saw (N > 1): a SCALE record must not rest on this file's own `world` variable ----
+    if use_pg:
+        ck = torch.tensor([float(rank), 1.0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ck, op=dist.ReduceOp.SUM)                  # through the same group the gradients use
+        names = [None] * dist.get_world_size()
+        dist.all_gather_object(names, f"{torch.cuda.get_device_name(dev)}#{local_dev}")
+        try:
+            rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:                                      # noqa: BLE001
+            rccl_version = f"unavailable: {e}"
+        gs = wrapped.module.runtime.grad_sync
+        result["comm"] = {"world_size": dist.get_world_size(), "backend": str(dist.get_backend()),
+                          "rccl_version": rccl_version, "rank_checksum": float(ck[0]),
+                          "rank_checksum_expected": world * (world - 1) / 2.0, "ranks_counted": float(ck[1]),
+                          "devices": names, "grad_exchange": getattr(gs, "mode", None),
+                          "grad_buckets": getattr(gs, "n_buckets", None),
+                          "reserved_cus": getattr(gs, "reserved_cus", None),
+                          "note": "all-reduced over the default process group after the timed region: sum of ranks and "
+                                  "count of ranks as the collective library delivered them"}
+        if int(ck[1]) != world or float(ck[0]) != world * (world - 1) / 2.0:
+            raise SystemExit(f"bench.py: the process group reduced over {int(ck[1])} ranks (checksum {float(ck[0])}), "
+                             f"expected {world}")
+
     # ---- per-kernel-class attribution (HIP events on the launch stream, a few extra steps) ----
     if rank == 0 and not args.no_profile:
         ncls = fn("snx_prof_num_classes")()
@@ -401,6 +426,76 @@ def main():
                                    "backward (snx.encoder.StepArena; SNX_STEP_ARENA=0: three independent passes, "
                                    "1,145 triplets/s in round 5); `value` above runs the three batches as one native "
                                    "pass and keeps the loss on the device"}
+
+    # ---- the step where training actually lives: a trained model's output sparsity ----
+    # At random init every (sequence, vocabulary) entry of the pooled output is active, the worst case of the arg-max-routed
+    # decoder backward (and the only case `value` sees).  The reference's trained model has ~54 active dimensions per
+    # document and ~33 per query (ref:huggingface/v33/README.md:240-245; the FLOPS regulariser ref:src/model/losses.py:57-73
+    # drives it there).  This leg shifts the decoder bias by one scalar so that the positives of batch 0 keep 54 active
+    # dimensions on average, times the same micro-step, and restores the bias.  Reported under `extra`; headline untouched.
+    if not args.no_sparse_regime_leg:
+        from torch.amp import autocast
+        bias = model.model.decoder.bias
+        saved_bias = bias.detach().clone()
+        b0 = batches[0]
+        with torch.no_grad(), autocast(device_type="cuda", dtype=torch.bfloat16):
+            (_, _), (p_rep, _) = model.forward_many([(b0["query_input_ids"], b0["query_attention_mask"]),
+                                                     (b0["positive_input_ids"], b0["positive_attention_mask"])])
+        kth = torch.topk(torch.expm1(p_rep.float()), 55, dim=-1).values[:, -1].mean().reshape(1)   # pooled logit of rank 55
+        if use_pg:
+            src_dev = kth if backend == "nccl" else kth.cpu()
+            dist.broadcast(src_dev, src=0)                          # one shift for every rank: replicas stay identical
+            kth = src_dev.to(dev)
+        with torch.no_grad():
+            bias.sub_(kth)
+        wrapped.zero_grad()
+        while state["i"] % args.accum:
+            one_step()
+        for _ in range(args.accum):
+            one_step()
+        barrier()
+        ks = max(args.accum, min(args.steps, 4 * args.accum))
+        t0 = time.perf_counter()
+        for _ in range(ks):
+            one_step()
+        barrier()
+        dtsp = time.perf_counter() - t0
+        if use_pg:
+            tmax = torch.tensor([dtsp], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dtsp = float(tmax.item())
+        leg = {"ms_per_step": 1000.0 * dtsp / ks, "value": ks * B * world / dtsp, "steps": ks,
+               "bias_shift": -float(kth.item())}
+        b_last = batches[state["i"] % n_batches]
+        _, ld = T.micro_step(wrapped, loss_fn, b_last, state["gs"], dev, args.accum, xneg,
+                             last_of_window=(state["i"] + 1) % args.accum == 0)
+        state["i"] += 1
+        if state["i"] % args.accum == 0:
+            T.optimizer_step(wrapped, optimizer, scheduler, config)
+            state["gs"] += 1
+        leg["active_dims_query"], leg["active_dims_doc"] = float(ld["nonzero_q"]), float(ld["nonzero_d"])
+        if rank == 0 and not args.no_profile:
+            ncls = fn("snx_prof_num_classes")()
+            names = [fn("snx_prof_class_name")(i).decode() for i in range(ncls)]
+            fn("snx_prof_enable")(1)
+            for _ in range(args.accum):
+                one_step()
+            torch.cuda.synchronize()
+            ms = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)(); work = (C.c_double * ncls)()
+            fn("snx_prof_read")(ms, cnt, work)
+            fn("snx_prof_enable")(0)
+            leg["kernel_class_ms_per_step"] = {nme: ms[i] / args.accum for i, nme in enumerate(names) if cnt[i]
+                                               and nme in ("splade_bwd", "decoder_splade_fwd", "embed_ln", "gemm_tn_accum")}
+        elif world > 1 and not args.no_profile:
+            for _ in range(args.accum):
+                one_step()
+            torch.cuda.synchronize()
+        with torch.no_grad():
+            bias.copy_(saved_bias)
+        leg["note"] = ("same micro-step with the decoder bias shifted by one scalar so that ~54 vocabulary dimensions per "
+                       "document stay active (the trained model's regime, ref:huggingface/v33/README.md:240-245) instead of "
+                       "all 50,000 (random init, the headline's worst case for the arg-max-routed decoder backward)")
+        result.setdefault("extra", {})["sparse_regime"] = leg
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()

@@ -173,17 +173,20 @@ int snx_sparse_topk(const float* rep, const uint8_t* allowed, float* out_val, in
 /* dims [host] = {B, Bp, k, V, label_off, bf16_mm}: q [B,V], p [Bp,V] (Bp > B: all-gathered
  * positives for cross-GPU in-batch negatives, own rows start at label_off), n [B*k,V]; bf16_mm=1
  * rounds the operands of the in-batch mm to bf16 as autocast does (ref:losses.py:155).
- * hp [host] = {temperature, lambda_q(t), lambda_d(t), lambda_neg(t), lambda_margin_mse}
+ * hp [host] = {temperature, lambda_q(t), lambda_d(t), lambda_neg(t), lambda_margin_mse, lambda_kd, kd_temperature}
  * (the lambda schedule ref:losses.py:75-90 is evaluated by the host caller).
  * tpos [B], tneg [B*k] teacher scores or NULL (MarginMSE, ref:losses.py:92-134).
- * out8 = {loss, infonce, flops_q, flops_d, flops_neg, margin_mse, nonzero_q, nonzero_d}. */
+ * tscores [B,B] teacher score matrix or NULL (KL distillation against the rank's own positives, ref:losses.py:239-253:
+ * batchmean KL(softmax(tscores / T_kd) || softmax(q p^T / T_kd)), active when lambda_kd > 0 and tscores != NULL).
+ * out9 = {loss, infonce, flops_q, flops_d, flops_neg, margin_mse, nonzero_q, nonzero_d, kd}. */
 size_t snx_loss_workspace_bytes(int32_t B, int32_t Bp, int32_t k, int32_t V);
 int snx_loss_fwd(const float* q, const float* p, const float* n, const float* tpos, const float* tneg,
-                 const float* hp /*[host]*/, const int32_t* dims /*[host]*/, void* workspace, float* out8,
-                 hipStream_t stream);
-/* gout = dL/dloss (device scalar); dq [B,V], dp [Bp,V], dn [B*k,V] are overwritten. */
+                 const float* tscores, const float* hp /*[host]*/, const int32_t* dims /*[host]*/, void* workspace,
+                 float* out9, hipStream_t stream);
+/* gout = dL/dloss (device scalar); dq [B,V], dp [Bp,V], dn [B*k,V] are overwritten.  use_kd != 0: the forward that
+ * filled `workspace` was given tscores with lambda_kd > 0. */
 int snx_loss_bwd(const float* q, const float* p, const float* n, const float* gout, const float* hp /*[host]*/,
-                 const int32_t* dims /*[host]*/, void* workspace, float* dq, float* dp, float* dn,
+                 const int32_t* dims /*[host]*/, void* workspace, int32_t use_kd, float* dq, float* dp, float* dn,
                  hipStream_t stream);
 
 /* ---- individual ops (used by the entry points above; exported for parity tests) ---------- */

@@ -484,6 +484,15 @@ __global__ void embed_fill_kernel(const int64_t* __restrict__ ids, const int* __
   const long id = ids[t];
   if (id != pad_id && id >= 0 && id < V) list[off[id] + atomicAdd(fill + id, 1)] = t;
 }
+// Ids that own more than EMBED_HEAVY tokens of the call ("heavy": [CLS] / [SEP] once per sequence, the frequent tokens of
+// Zipfian text -- several percent of T each) leave the per-token kernels: a serial walk over such a list by ONE wave is a
+// millisecond-class tail at the end of the backward, and ranking it by comparisons is n^2.  They are ranked by a bitmap
+// and summed in two FIXED levels instead (embed_heavy_* below).  Light ids keep the per-token path: rank by <= 64
+// comparisons, the id's first token adds its rows in ascending token order.
+constexpr int EMBED_HEAVY = 64;        // an id with more tokens than this is heavy
+constexpr int EMBED_CHUNK = 32;        // tokens per partial row of a heavy id
+constexpr int EMBED_WINDOW = 65536;    // token indices per bitmap window (8 KiB of LDS)
+
 __global__ void embed_rank_kernel(const int64_t* __restrict__ ids, const int* __restrict__ off, const int* __restrict__ list,
                                   int* __restrict__ sorted, int T, int V, int pad_id) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -491,6 +500,7 @@ __global__ void embed_rank_kernel(const int64_t* __restrict__ ids, const int* __
   const long id = ids[t];
   if (id == pad_id || id < 0 || id >= V) return;
   const int b = off[id], e = off[id + 1];
+  if (e - b > EMBED_HEAVY) return;                     // ranked by embed_heavy_sort_kernel
   int r = 0;
   for (int j = b; j < e; ++j) r += list[j] < t;
   sorted[b + r] = t;
@@ -505,6 +515,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restr
   const long id = ids[t];
   if (id == pad_id || id < 0 || id >= V) return;
   const int b = off[id], e = off[id + 1];
+  if (e - b > EMBED_HEAVY) return;                     // summed by embed_heavy_chunk_kernel / embed_heavy_final_kernel
   if (sorted[b] != t) return;                          // only the id's first token adds
   RowVec<NV> acc, row;
   acc.load_f32(gradE + id * (long)H, lane);
@@ -516,24 +527,174 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restr
   acc.store_f32(gradE + id * (long)H, lane);
 }
 
+// ---- heavy ids -------------------------------------------------------------------------------------------------------
+// collect: one thread per id; a heavy id takes a slot (which slot: arrival order -- it only places the id's partial rows in
+// the workspace, no sum depends on it) and a run of cdiv(n, EMBED_CHUNK) chunk rows.
+__global__ void embed_heavy_collect_kernel(const int* __restrict__ cnt, int* __restrict__ counters, int* __restrict__ heavy_id,
+                                           int* __restrict__ heavy_chunk0, int V) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const int n = cnt[v];
+  if (n <= EMBED_HEAVY) return;
+  const int slot = atomicAdd(counters + 0, 1);
+  heavy_id[slot] = v;
+  heavy_chunk0[slot] = atomicAdd(counters + 1, (n + EMBED_CHUNK - 1) / EMBED_CHUNK);
+}
+// sort: one workgroup per heavy slot.  The id's token list (arrival order) becomes ascending order through a bitmap over
+// token indices in LDS: set the bits, scan the words' popcounts, emit.  n entries + T / 32 words of work whatever n is;
+// windows of EMBED_WINDOW indices keep the LDS footprint fixed for any T.  Also describes the id's chunks for the sum.
+__global__ __launch_bounds__(256) void embed_heavy_sort_kernel(const int* __restrict__ counters, const int* __restrict__ heavy_id,
+                                                               const int* __restrict__ heavy_chunk0,
+                                                               const int* __restrict__ off, const int* __restrict__ list,
+                                                               int* __restrict__ sorted, int* __restrict__ chunk_desc, int T) {
+  constexpr int WORDS = EMBED_WINDOW / 32, WPT = WORDS / 256;
+  __shared__ uint32_t bits[WORDS];
+  __shared__ int wsum[4];
+  __shared__ int run_base;
+  const int slot = blockIdx.x;
+  if (slot >= counters[0]) return;
+  const int id = heavy_id[slot];
+  const int b = off[id], e = off[id + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < (e - b + EMBED_CHUNK - 1) / EMBED_CHUNK; c += 256) {
+    int* dsc = chunk_desc + 3 * (long)(heavy_chunk0[slot] + c);
+    dsc[0] = b + c * EMBED_CHUNK;
+    dsc[1] = min(EMBED_CHUNK, e - b - c * EMBED_CHUNK);
+    dsc[2] = id;
+  }
+  if (threadIdx.x == 0) run_base = 0;
+  for (int w0 = 0; w0 < T; w0 += EMBED_WINDOW) {
+    for (int i = threadIdx.x; i < WORDS; i += 256) bits[i] = 0u;
+    __syncthreads();
+    for (int j = b + threadIdx.x; j < e; j += 256) {
+      const int t = list[j] - w0;
+      if (t >= 0 && t < EMBED_WINDOW) atomicOr(bits + (t >> 5), 1u << (t & 31));
+    }
+    __syncthreads();
+    uint32_t w[WPT];
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) { w[i] = bits[threadIdx.x * WPT + i]; c += __popc(w[i]); }
+    int inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = run_base;
+    for (int q = 0; q < wave; ++q) base += wsum[q];
+    int k = b + base + inc - c;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      uint32_t x = w[i];
+      while (x) {
+        const int bit = __ffs((int)x) - 1;
+        sorted[k++] = w0 + (threadIdx.x * WPT + i) * 32 + bit;
+        x &= x - 1;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) run_base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+}
+// level 1: one wave per chunk sums its <= EMBED_CHUNK dx rows in ascending token order into a partial row (indices and
+// rows eight at a time: independent loads in flight, the adds stay in order).
+template <int NV>
+__global__ __launch_bounds__(256) void embed_heavy_chunk_kernel(const float* __restrict__ dx, const int* __restrict__ counters,
+                                                                const int* __restrict__ chunk_desc,
+                                                                const int* __restrict__ sorted, float* __restrict__ partial,
+                                                                int H) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= counters[1]) return;
+  const int b = chunk_desc[3 * (long)c], n = chunk_desc[3 * (long)c + 1];
+  RowVec<NV> acc;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc.v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int j = 0;
+  for (; j + 8 <= n; j += 8) {
+    int tk[8];
+    RowVec<NV> row[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tk[q] = sorted[b + j + q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) row[q].load_f32(dx + (long)tk[q] * H, lane);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc.v[i] += row[q].v[i];
+  }
+  for (; j < n; ++j) {
+    RowVec<NV> row;
+    row.load_f32(dx + (long)sorted[b + j] * H, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc.v[i] += row.v[i];
+  }
+  acc.store_f32(partial + (long)c * H, lane);
+}
+// level 2: one wave per heavy id adds the id's partial rows to its gradient row in chunk order.
+template <int NV>
+__global__ __launch_bounds__(256) void embed_heavy_final_kernel(const float* __restrict__ partial, const int* __restrict__ counters,
+                                                                const int* __restrict__ heavy_id,
+                                                                const int* __restrict__ heavy_chunk0, const int* __restrict__ off,
+                                                                float* __restrict__ gradE, int H) {
+  const int lane = threadIdx.x & 63;
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slot >= counters[0]) return;
+  const int id = heavy_id[slot];
+  const int nch = (off[id + 1] - off[id] + EMBED_CHUNK - 1) / EMBED_CHUNK;
+  const float* src = partial + (long)heavy_chunk0[slot] * H;
+  RowVec<NV> acc;
+  acc.load_f32(gradE + id * (long)H, lane);
+  int c = 0;
+  for (; c + 4 <= nch; c += 4) {
+    RowVec<NV> row[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) row[q].load_f32(src + (long)(c + q) * H, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc.v[i] += row[q].v[i];
+  }
+  for (; c < nch; ++c) {
+    RowVec<NV> row;
+    row.load_f32(src + (long)c * H, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc.v[i] += row.v[i];
+  }
+  acc.store_f32(gradE + id * (long)H, lane);
+}
+static inline int embed_max_heavy(int T) { return T / (EMBED_HEAVY + 1) + 1; }
+static inline int embed_max_chunks(int T) { return T / EMBED_CHUNK + embed_max_heavy(T) + 1; }
+
 static inline int ln_bwd_rows_per_block(int T) {
   int rpb = cdiv(T, 1024);                 // ~1024 blocks: 4 per CU
   rpb = ((rpb + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * ROWS_PER_BLOCK;
   return rpb < ROWS_PER_BLOCK ? ROWS_PER_BLOCK : rpb;
 }
 
-// partial dw rows of one LayerNorm backward launch (one per block)
+// partial dw rows of one LayerNorm backward launch (one per block).  The launch's block count cdiv(T, rows_per_block(T))
+// is NOT monotone in T (8,192 rows: 1,024 blocks; 9,000 rows: 750), and a workspace planned for T_plan rows must serve
+// every backward over T <= T_plan rows (the micro-step arena, snx_model_backward_units_range): the size is therefore the
+// MONOTONE bound min(cdiv(T, 4), 1024) rows -- exact up to 4,096 rows, the block-count ceiling above.
 extern "C" size_t snx_ln_bwd_workspace_bytes(int32_t T, int32_t H) {
   if (T <= 0 || H <= 0) return 0;
-  return (size_t)cdiv(T, ln_bwd_rows_per_block(T)) * H * 4;
+  const int nb_bound = cdiv(T, ROWS_PER_BLOCK) < 1024 ? cdiv(T, ROWS_PER_BLOCK) : 1024;
+  return (size_t)nb_bound * H * 4;
 }
 // + the dx rows and the per-id token lists of the embedding gradient's ordered sum
 extern "C" size_t snx_embed_ln_bwd_workspace_bytes(int32_t T, int32_t H, int32_t V) {
   if (T <= 0 || H <= 0 || V <= 0) return 0;
   const size_t a = (snx_ln_bwd_workspace_bytes(T, H) + 255) & ~(size_t)255;
   const size_t rows = ((size_t)T * H * 4 + 255) & ~(size_t)255;
-  const size_t ints = ((size_t)(3 * (size_t)V + 1 + 2 * (size_t)T) * 4 + 255) & ~(size_t)255;
-  return a + rows + ints;
+  // cnt[V] fill[V] counters[2] (zeroed together) off[V + 1] list[T] sorted[T] heavy_id[mh] heavy_chunk0[mh] chunk_desc[3 mc]
+  const size_t mh = embed_max_heavy(T), mc = embed_max_chunks(T);
+  const size_t ints = ((size_t)(3 * (size_t)V + 3 + 2 * (size_t)T + 2 * mh + 3 * mc) * 4 + 255) & ~(size_t)255;
+  const size_t partial = (mc * (size_t)H * 4 + 255) & ~(size_t)255;
+  return a + rows + ints + partial;
 }
 
 // `defer` (the model's backward): the partial rows stay in `part` and the caller reduces them later, batched
@@ -595,20 +756,29 @@ int snx_embed_ln_bwd_x(const float* dh, const int64_t* ids, const float* E, cons
   const int rpb = ln_bwd_rows_per_block(T);
   const int nb = cdiv(T, rpb);
   LN_WS(snx_embed_ln_bwd_workspace_bytes(T, H, V));
-  float* dxrows = nullptr;
-  int *cnt = nullptr, *fill = nullptr, *off = nullptr, *list = nullptr, *sorted = nullptr;
+  float *dxrows = nullptr, *partial = nullptr;
+  int *cnt = nullptr, *fill = nullptr, *counters = nullptr, *off = nullptr, *list = nullptr, *sorted = nullptr;
+  int *heavy_id = nullptr, *heavy_chunk0 = nullptr, *chunk_desc = nullptr;
+  const int mh = embed_max_heavy(T), mc = embed_max_chunks(T);
   if (part) {
     char* base = (char*)ws;
     size_t o = (snx_ln_bwd_workspace_bytes(T, H) + 255) & ~(size_t)255;
     dxrows = (float*)(base + o);
     o += ((size_t)T * H * 4 + 255) & ~(size_t)255;
-    cnt = (int*)(base + o); fill = cnt + V; off = fill + V; list = off + V + 1; sorted = list + T;
-    if (hipMemsetAsync(cnt, 0, (size_t)2 * V * 4, st) != hipSuccess) return SNX_E_ARG;
+    cnt = (int*)(base + o); fill = cnt + V; counters = fill + V; off = counters + 2; list = off + V + 1; sorted = list + T;
+    heavy_id = sorted + T; heavy_chunk0 = heavy_id + mh; chunk_desc = heavy_chunk0 + mh;
+    o += ((size_t)(3 * (size_t)V + 3 + 2 * (size_t)T + 2 * (size_t)mh + 3 * (size_t)mc) * 4 + 255) & ~(size_t)255;
+    partial = (float*)(base + o);
+    if (hipMemsetAsync(cnt, 0, ((size_t)2 * V + 2) * 4, st) != hipSuccess) return SNX_E_ARG;
     hipLaunchKernelGGL(embed_count_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, ids, cnt, T, V, pad_id);
     hipLaunchKernelGGL(embed_scan_kernel, dim3(cdiv(V, 1024)), dim3(1024), 0, st, (const int*)cnt, off, V);
     hipLaunchKernelGGL(embed_fill_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, ids, (const int*)off, fill, list, T, V, pad_id);
     hipLaunchKernelGGL(embed_rank_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, ids, (const int*)off, (const int*)list,
                        sorted, T, V, pad_id);
+    hipLaunchKernelGGL(embed_heavy_collect_kernel, dim3(cdiv(V, 256)), dim3(256), 0, st, (const int*)cnt, counters, heavy_id,
+                       heavy_chunk0, V);
+    hipLaunchKernelGGL(embed_heavy_sort_kernel, dim3(mh), dim3(256), 0, st, (const int*)counters, (const int*)heavy_id,
+                       (const int*)heavy_chunk0, (const int*)off, (const int*)list, sorted, chunk_desc, T);
     SNX_CHECK_LAUNCH();
   }
   DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 1>), dim3(nb), dim3(256), 0, st, nullptr, dh,
@@ -618,6 +788,11 @@ int snx_embed_ln_bwd_x(const float* dh, const int64_t* ids, const float* E, cons
   if (!part) return SNX_OK;
   DISPATCH_NV(H, hipLaunchKernelGGL((embed_scatter_kernel<NV>), dim3(cdiv(T, 4)), dim3(256), 0, st, (const float*)dxrows,
                                     ids, (const int*)off, (const int*)sorted, gradE, T, H, V, pad_id));
+  DISPATCH_NV(H, hipLaunchKernelGGL((embed_heavy_chunk_kernel<NV>), dim3(cdiv(mc, 4)), dim3(256), 0, st, (const float*)dxrows,
+                                    (const int*)counters, (const int*)chunk_desc, (const int*)sorted, partial, H));
+  DISPATCH_NV(H, hipLaunchKernelGGL((embed_heavy_final_kernel<NV>), dim3(cdiv(mh, 4)), dim3(256), 0, st, (const float*)partial,
+                                    (const int*)counters, (const int*)heavy_id, (const int*)heavy_chunk0, (const int*)off,
+                                    gradE, H));
   SNX_CHECK_LAUNCH();
   return ln_dw_finish(part, dw, nb, H, st, defer, ndefer);
 }

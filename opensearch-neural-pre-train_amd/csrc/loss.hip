@@ -1,6 +1,7 @@
 // SPLADELossV33 on device (K12-K15 of SURVEY.md §2.3; ref:src/model/losses.py:57-297):
 //   InfoNCE over [in-batch positives | k hard negatives] + FLOPS(q) + FLOPS(pos) + FLOPS(neg)
-//   [+ MarginMSE], closed-form gradients, no host sync (scalars stay on the device).
+//   [+ MarginMSE] [+ KL distillation, ref:losses.py:239-253], closed-form gradients, no host sync (scalars stay on the
+//   device).
 // Three launches: (1) per-vocab-chunk partial dot products / column means (LDS-staged tiles,
 // coalesced along V), (2) one workgroup reducing the partials, soft-max / cross-entropy and the
 // gradient coefficients, (3) the gradient of the three [*, V] inputs, again chunked over V.
@@ -11,7 +12,7 @@
 
 struct LossDims {
   int B, Bp, k, V, CH, nchunk, label_off, bf16_mm;
-  float inv_tau, lam_q, lam_d, lam_neg, lam_mm;
+  float inv_tau, lam_q, lam_d, lam_neg, lam_mm, lam_kd, inv_tkd;
 };
 
 // workspace layout (floats)
@@ -19,11 +20,13 @@ struct LossWs {
   float *part_inb, *part_hard, *part_pos, *part_sc;   // [nchunk][B*Bp], [nchunk][B*k], [nchunk][B], [nchunk][8]
   float *mean_q, *mean_p, *mean_n;                     // [V] each
   float *G, *Gh, *dpos;                                // [B*Bp], [B*k], [B]
+  float *Gkd;                                          // [B*B] coefficients of the KL-distillation term (own positives)
   float *red;                                          // [B*Bp + B*k + B] partials summed over chunks
 };
 
 static inline size_t ws_floats(int B, int Bp, int k, int V, int nchunk) {
-  return (size_t)nchunk * ((size_t)B * Bp + (size_t)B * k + B + 8) + 3 * (size_t)V + 2 * ((size_t)B * Bp + (size_t)B * k + B);
+  return (size_t)nchunk * ((size_t)B * Bp + (size_t)B * k + B + 8) + 3 * (size_t)V + 2 * ((size_t)B * Bp + (size_t)B * k + B) +
+         (size_t)B * B;
 }
 static inline LossWs carve(float* w, int B, int Bp, int k, int V, int nchunk) {
   LossWs s;
@@ -37,6 +40,7 @@ static inline LossWs carve(float* w, int B, int Bp, int k, int V, int nchunk) {
   s.G = w; w += (size_t)B * Bp;
   s.Gh = w; w += (size_t)B * k;
   s.dpos = w; w += B;
+  s.Gkd = w; w += (size_t)B * B;
   s.red = w;
   return s;
 }
@@ -177,9 +181,10 @@ __global__ void loss_sum_partials_kernel(LossDims d, LossWs w) {
   w.red[o] = (s0 + s1) + (s2 + s3);
 }
 
-// out[0]=loss [1]=infonce [2]=flops_q [3]=flops_d [4]=flops_neg [5]=margin_mse [6]=nonzero_q [7]=nonzero_d
+// out[0]=loss [1]=infonce [2]=flops_q [3]=flops_d [4]=flops_neg [5]=margin_mse [6]=nonzero_q [7]=nonzero_d [8]=kd
 __global__ __launch_bounds__(256) void loss_reduce_kernel(LossDims d, LossWs w, const float* __restrict__ tpos,
-                                                          const float* __restrict__ tneg, float* __restrict__ out) {
+                                                          const float* __restrict__ tneg,
+                                                          const float* __restrict__ tsc, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ float red[4];
   const int tid = threadIdx.x;
@@ -205,8 +210,38 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossDims d, LossWs w, 
   for (int e = 0; e < 5; ++e) tot[e] = block_sum(sca[e], red);
   __syncthreads();
   // cross entropy, one row per thread; soft-max gradient coefficients
-  float ce = 0.f, mm = 0.f;
+  float ce = 0.f, mm = 0.f, kd = 0.f;
+  const bool use_kd = d.lam_kd > 0.f && tsc;
   for (int i = tid; i < d.B; i += 256) {
+    if (use_kd) {
+      // KL(teacher || student), batchmean (ref:losses.py:241-253): student = (q . own positives) / T_kd -- the SAME in-batch
+      // dots as InfoNCE's (bf16-rounded under autocast: the reference's second torch.mm rounds alike) --, teacher =
+      // softmax(teacher_scores / T_kd).  d kd / d s_ij = (softmax(s)_ij - teacher_ij) / B.
+      const float* dots = w.red + (long)i * d.Bp + d.label_off;
+      const float* tr = tsc + (long)i * d.B;
+      float ms = -INFINITY, mt = -INFINITY;
+      for (int j = 0; j < d.B; ++j) {
+        const float sv = (d.bf16_mm ? rbf(dots[j]) : dots[j]) * d.inv_tkd;
+        ms = fmaxf(ms, sv);
+        mt = fmaxf(mt, tr[j] * d.inv_tkd);
+      }
+      float es = 0.f, et = 0.f;
+      for (int j = 0; j < d.B; ++j) {
+        es += expf((d.bf16_mm ? rbf(dots[j]) : dots[j]) * d.inv_tkd - ms);
+        et += expf(tr[j] * d.inv_tkd - mt);
+      }
+      const float lse_s = ms + logf(es), lse_t = mt + logf(et);
+      const float gk = d.lam_kd * d.inv_tkd / (float)d.B;
+      for (int j = 0; j < d.B; ++j) {
+        const float ls = (d.bf16_mm ? rbf(dots[j]) : dots[j]) * d.inv_tkd - lse_s;
+        const float lt = tr[j] * d.inv_tkd - lse_t;
+        const float pt = expf(lt);
+        if (pt > 0.f) kd += pt * (lt - ls);                  // xlogy: a zero teacher probability contributes nothing
+        float gv = (expf(ls) - pt) * gk;
+        if (d.bf16_mm) gv = rbf(gv);
+        w.Gkd[(long)i * d.B + j] = gv;
+      }
+    }
     float* row = sc + i * NS;
     float mx = row[0];
     for (int j = 1; j < NS; ++j) mx = fmaxf(mx, row[j]);
@@ -239,12 +274,14 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossDims d, LossWs w, 
   }
   ce = block_sum(ce, red);
   mm = block_sum(mm, red);
+  kd = block_sum(kd, red);
   if (tid == 0) {
     const float infonce = ce / (float)d.B;
     const float mmse = mm / (float)(d.B * d.k);
+    const float kdl = kd / (float)d.B;
     out[1] = infonce; out[2] = tot[0]; out[3] = tot[1]; out[4] = tot[2]; out[5] = mmse;
-    out[6] = tot[3] / (float)d.B; out[7] = tot[4] / (float)d.B;
-    out[0] = infonce + d.lam_q * tot[0] + d.lam_d * tot[1] + d.lam_neg * tot[2] +
+    out[6] = tot[3] / (float)d.B; out[7] = tot[4] / (float)d.B; out[8] = use_kd ? kdl : 0.f;
+    out[0] = infonce + d.lam_q * tot[0] + d.lam_d * tot[1] + d.lam_neg * tot[2] + (use_kd ? d.lam_kd * kdl : 0.f) +
              ((d.lam_mm > 0.f && tpos && tneg) ? d.lam_mm * mmse : 0.f);
   }
 }
@@ -252,7 +289,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossDims d, LossWs w, 
 // gradients of the three inputs; gout = dL/dloss (device scalar)
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ q, const float* __restrict__ p,
                                                        const float* __restrict__ n, const float* __restrict__ gout,
-                                                       LossDims d, LossWs w, float* __restrict__ dq,
+                                                       LossDims d, LossWs w, int use_kd, float* __restrict__ dq,
                                                        float* __restrict__ dp, float* __restrict__ dn) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int LD = d.CH + 1;
@@ -291,6 +328,14 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
         const int i = i0 + u;
         if (i >= d.B) break;
         float r = d.bf16_mm ? rbf(s[u]) : s[u];
+        if (use_kd) {                                        // the KD term's own mm backward (a second bf16 product under autocast)
+          float s2 = 0.f;
+          for (int j = 0; j < d.B; ++j) {
+            const float pv = d.bf16_mm ? rbf(sp[(d.label_off + j) * LD + c]) : sp[(d.label_off + j) * LD + c];
+            s2 += w.Gkd[(long)i * d.B + j] * pv;
+          }
+          r += d.bf16_mm ? rbf(s2) : s2;
+        }
         for (int kk = 0; kk < d.k; ++kk) r += w.Gh[i * d.k + kk] * n[(long)(i * d.k + kk) * d.V + c0 + c];
         r += w.dpos[i] * sp[(d.label_off + i) * LD + c] + fq * w.mean_q[c0 + c];
         dq[(long)i * d.V + c0 + c] = go * r;
@@ -312,6 +357,11 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
         if (j >= d.Bp) break;
         float r = d.bf16_mm ? rbf(s[u]) : s[u];
         const int il = j - d.label_off;
+        if (use_kd && il >= 0 && il < d.B) {
+          float s2 = 0.f;
+          for (int i = 0; i < d.B; ++i) s2 += w.Gkd[(long)i * d.B + il] * (d.bf16_mm ? rbf(sq[i * LD + c]) : sq[i * LD + c]);
+          r += d.bf16_mm ? rbf(s2) : s2;
+        }
         if (il >= 0 && il < d.B) r += w.dpos[il] * sq[il * LD + c] + fd * w.mean_p[c0 + c];
         dp[(long)j * d.V + c0 + c] = go * r;
       }
@@ -333,6 +383,7 @@ static int make_dims(LossDims& d, int B, int Bp, int k, int V, int label_off, in
   d.CH = pick_ch(B, Bp);
   d.nchunk = cdiv(V, d.CH);
   d.inv_tau = 1.0f / hp[0]; d.lam_q = hp[1]; d.lam_d = hp[2]; d.lam_neg = hp[3]; d.lam_mm = hp[4];
+  d.lam_kd = hp[5]; d.inv_tkd = hp[6] > 0.f ? 1.0f / hp[6] : 1.0f;
   if ((size_t)(B * (Bp + k) + B * k + B) * 4 > 150 * 1024) return SNX_E_SHAPE;
   return SNX_OK;
 }
@@ -343,11 +394,13 @@ extern "C" size_t snx_loss_workspace_bytes(int32_t B, int32_t Bp, int32_t k, int
   return ws_floats(B, Bp, k, V, cdiv(V, ch)) * sizeof(float);
 }
 
-// hp = {temperature, lambda_q(t), lambda_d(t), lambda_neg(t), lambda_margin_mse}  (host floats)
+// hp = {temperature, lambda_q(t), lambda_d(t), lambda_neg(t), lambda_margin_mse, lambda_kd, kd_temperature}  (host floats)
 // dims = {B, Bp, k, V, label_off, bf16_mm}
 extern "C" int snx_loss_fwd(const float* q, const float* p, const float* n, const float* tpos, const float* tneg,
-                            const float* hp, const int32_t* dims, void* workspace, float* out8, hipStream_t st) {
-  if (!q || !p || !n || !hp || !dims || !workspace || !out8) return SNX_E_ARG;
+                            const float* tscores, const float* hp, const int32_t* dims, void* workspace, float* out9,
+                            hipStream_t st) {
+  if (!q || !p || !n || !hp || !dims || !workspace || !out9) return SNX_E_ARG;
+  float* out8 = out9;
   LossDims d;
   int rc = make_dims(d, dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], hp);
   if (rc) return rc;
@@ -358,20 +411,23 @@ extern "C" int snx_loss_fwd(const float* q, const float* p, const float* n, cons
   hipLaunchKernelGGL(loss_sum_partials_kernel, dim3(cdiv(d.B * d.Bp + d.B * d.k + d.B, 256)), dim3(256), 0, st, d, w);
   SNX_CHECK_LAUNCH();
   const size_t lds2 = (size_t)(d.B * (d.Bp + d.k) + d.B * d.k + d.B) * 4;
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), lds2, st, d, w, tpos, tneg, out8);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), lds2, st, d, w, tpos, tneg, tscores, out8);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }
 
+// use_kd: the forward was given teacher scores with lambda_kd > 0 (its coefficients are in the workspace)
 extern "C" int snx_loss_bwd(const float* q, const float* p, const float* n, const float* gout, const float* hp,
-                            const int32_t* dims, void* workspace, float* dq, float* dp, float* dn, hipStream_t st) {
+                            const int32_t* dims, void* workspace, int32_t use_kd, float* dq, float* dp, float* dn,
+                            hipStream_t st) {
   if (!q || !p || !n || !gout || !hp || !dims || !workspace || !dq || !dp || !dn) return SNX_E_ARG;
   LossDims d;
   int rc = make_dims(d, dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], hp);
   if (rc) return rc;
   LossWs w = carve((float*)workspace, d.B, d.Bp, d.k, d.V, d.nchunk);
   const size_t lds = (size_t)(d.B + d.Bp) * (d.CH + 1) * 4;
-  hipLaunchKernelGGL(loss_bwd_kernel, dim3(d.nchunk), dim3(256), lds, st, q, p, n, gout, d, w, dq, dp, dn);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(d.nchunk), dim3(256), lds, st, q, p, n, gout, d, w,
+                     (use_kd && d.lam_kd > 0.f) ? 1 : 0, dq, dp, dn);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }

@@ -63,8 +63,8 @@ SIGNATURES = {
     "snx_decoder_splade_fwd_ex": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
     "snx_splade_bwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P]),
     "snx_loss_workspace_bytes": (SZ, [I32, I32, I32, I32]),
-    "snx_loss_fwd": (I32, [P, P, P, P, P, P, P, P, P, P]),
-    "snx_loss_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P]),
+    "snx_loss_fwd": (I32, [P, P, P, P, P, P, P, P, P, P, P]),
+    "snx_loss_bwd": (I32, [P, P, P, P, P, P, P, I32, P, P, P, P]),
     "snx_model_workspace_bytes": (SZ, [P, I32, I32, I32]),
     "snx_model_bwd_workspace_bytes": (SZ, [P, I32, I32, I32]),
     "snx_splade_bwd_scratch_bytes": (SZ, [I32, I32, I32]),

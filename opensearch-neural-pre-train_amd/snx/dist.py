@@ -296,7 +296,65 @@ class _AllGatherRows(torch.autograd.Function):
 
 
 def all_gather_with_grad(x: torch.Tensor) -> torch.Tensor:
-    """[B, V] per rank -> [world*B, V] (rank-major), differentiable."""
+    """[B, V] per rank -> [world*B, V] (rank-major), differentiable.  Inline on the current stream."""
     if not active():
         return x
     return _AllGatherRows.apply(x)
+
+
+class _AllGatherRowsOnExchangeStream(torch.autograd.Function):
+    """_AllGatherRows with the collective issued on the EXCHANGE stream (collective 2: "issue on a side
+    stream after the positive pass so it hides under the negative pass").  forward() orders the exchange stream behind
+    what the compute stream has queued so far (the positive pass that produced `x`), issues the all-gather there and
+    returns at once: the compute stream goes on with the negative pass.  The result may be READ on the compute stream only
+    after `PendingGather.wait()` -- the one place the compute stream waits, right in front of the loss kernels.  Backward:
+    the reduce-scatter of the gathered gradient, inline (its result is needed at once by the positive pass's backward)."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, box: list):
+        w = world()
+        ctx.rows = x.shape[0]
+        x = x.contiguous()
+        dev = x.device
+        out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=dev)   # compute stream's allocation
+        side = exchange_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            if rccl():
+                dist.all_gather_into_tensor(out, x)
+            else:                                         # host-staged rehearsal (see rccl())
+                host = torch.empty(tuple(out.shape), dtype=x.dtype)
+                dist.all_gather_into_tensor(host, x.cpu())
+                out.copy_(host)
+            box.append(side.record_event())
+        x.record_stream(side)
+        out.record_stream(side)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: torch.Tensor):
+        return _AllGatherRows.backward(ctx, g), None
+
+
+class PendingGather:
+    """An all-gather in flight on the exchange stream; `wait()` makes the current stream wait for it and hands out the
+    gathered, differentiable tensor."""
+
+    def __init__(self, out: torch.Tensor, event):
+        self._out, self._event = out, event
+
+    def wait(self) -> torch.Tensor:
+        if self._event is not None:
+            torch.cuda.current_stream(self._out.device).wait_event(self._event)
+            self._event = None
+        return self._out
+
+
+def all_gather_with_grad_async(x: torch.Tensor) -> PendingGather:
+    """`all_gather_with_grad` whose collective runs on the exchange stream while the caller's stream continues; CPU tensors
+    (gloo host tests) and inactive groups degrade to the inline form.  Same values, same gradient as the inline form."""
+    if not active() or not x.is_cuda:
+        return PendingGather(all_gather_with_grad(x), None)
+    box: list = []
+    out = _AllGatherRowsOnExchangeStream.apply(x, box)
+    return PendingGather(out, box[0])

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import logging
 import os
+import weakref
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple  # noqa: F401
@@ -107,6 +108,14 @@ class EncoderRuntime:
         self._step_tot = [0, 0, 0]                           # token rows, sequences, passes of the micro-step in progress
         self._step_hist: list = []                           # totals of the last micro-steps
         self._arena: Optional["StepArena"] = None
+        # what the arena did, readable by the caller (a pass that leaves the arena costs ~15 % of the micro-step: it must
+        # not be silent).  placed: passes that went into an arena; fell_back: passes that ran on the ordinary path although
+        # a capacity had been learnt (did not fit / too many passes); zero_filled: placed passes whose output took no part in
+        # the loss (their gradient was back-propagated as zeros); stale_dropped: open arenas abandoned because a placed
+        # pass died without a backward or the weights changed under them.  The first fallback / zero fill / stale drop of
+        # a process also logs one warning.
+        self.arena_stats: Dict[str, int] = {"placed": 0, "fell_back": 0, "zero_filled": 0, "stale_dropped": 0}
+        self._arena_warned: set = set()
 
     # ------------------------------------------------------------------ parameter plumbing
     def _device(self):
@@ -467,24 +476,59 @@ class EncoderRuntime:
         self._step_forward(ids)
         return True
 
+    def _arena_note(self, what: str, msg: str) -> None:
+        self.arena_stats[what] += 1
+        if what not in self._arena_warned:
+            self._arena_warned.add(what)
+            logger.warning("snx micro-step arena: %s (counted in EncoderRuntime.arena_stats[%r]; further ones are only "
+                           "counted)", msg, what)
+
+    def _weights_key(self):
+        return tuple(p._version for p in self.params)
+
+    def _drop_stale_arena(self, a: "StepArena", why: str) -> None:
+        """An OPEN arena whose micro-step will never complete: a grad-enabled forward used for logging / evaluation, an
+        exception or a `continue` between the forwards and loss.backward().  Its live nodes (if any) keep working on their
+        own -- the arena back-propagates once all of them have reported -- but no further pass joins it, and the forwards
+        counted so far do not become a micro-step of the capacity history."""
+        a.closed = True
+        if self._arena is a:
+            self._arena = None
+        self._step_phase, self._step_tot = "bwd", [0, 0, 0]
+        self._arena_note("stale_dropped", "an open arena was abandoned (" + why + ")")
+
     def step_arena_place(self, ids: torch.Tensor, mask: torch.Tensor):
         """This pass into the micro-step's shared arena -> (sparse [B, V], token_weights [B*S], arena, index), or None when
-        no capacity has been learnt yet or the pass does not fit what is left of it (then it runs on the ordinary path)."""
+        no capacity has been learnt yet or the pass does not fit what is left of it (then it runs on the ordinary path,
+        which also owns the shape / length errors: an input the ordinary path would refuse is never placed)."""
         if not self._arena_eligible() or ids.dim() != 2 or mask.shape != ids.shape or ids.device != self._device() or \
                 mask.device != ids.device:
             return None
+        if ids.shape[1] > self.geom.max_position_embeddings or ids.shape[1] > 8192 or ids.shape[0] < 1 or ids.shape[1] < 1:
+            return None                                      # forward_many_impl raises "sequence too long"
+        a = self._arena
+        if a is not None and a.placed > 0:
+            why = a.stale_reason()
+            if why:
+                self._drop_stale_arena(a, why)
+                a = None
         cap = self.step_arena_capacity()
         if cap is None:
             return None
-        a = self._arena
         B, S = int(ids.shape[0]), int(ids.shape[1])
         if a is None:
             if B * S > cap[0] or B > cap[1]:
+                self._arena_note("fell_back", f"a pass of {B} x {S} tokens exceeds the learnt capacity {cap}: it runs on "
+                                 "the ordinary path (its own backward)")
                 return None
             a = self._arena = StepArena(self, cap[0], cap[1])
         if not a.fits(B, S):
+            self._arena_note("fell_back", f"a pass of {B} x {S} tokens does not fit what is left of the arena "
+                             f"({a.row0[-1]} of {a.T} rows, {a.seq0[-1]} of {a.nseq} sequences, {a.placed} passes used): it "
+                             "runs on the ordinary path (its own backward)")
             return None
         self._step_forward(ids)
+        self.arena_stats["placed"] += 1
         return a.place(ids, mask)
 
     def __call__(self, input_ids, attention_mask):
@@ -553,7 +597,32 @@ class StepArena:
             self.mask = torch.empty((self.T,), dtype=torch.int64, device=dev)
         self.placed = self.reported = 0
         self.grads: list = []
-        self.closed = self.done = False
+        self.nodes: list = []                                # weak references to the autograd nodes of the placed passes
+        self.got: list = []                                  # which of them have reported
+        self.wkey = None                                     # parameter versions the first placed pass computed with
+        self.closed = self.done = self.reporting = False
+
+    def attach(self, k: int, node) -> None:
+        """The autograd node (ctx) of placed pass k.  A node that dies without a backward (its outputs were only logged, an
+        exception unwound the micro-step) can never report: the arena learns that from the dead reference."""
+        try:
+            self.nodes[k] = weakref.ref(node)
+        except TypeError:                                    # a node type without weak references: never counted dead
+            self.nodes[k] = None
+
+    def dead(self) -> int:
+        return sum(1 for k, r in enumerate(self.nodes) if r is not None and not self.got[k] and r() is None)
+
+    def stale_reason(self) -> str:
+        """Why an OPEN arena (no backward yet) cannot be the micro-step in progress any more, or ''."""
+        if self.closed:
+            return ""
+        if self.dead():
+            return "a placed model(...) output was dropped without a backward"
+        rt = self.rt
+        if self.wkey is not None and (rt._wcache_key is None or rt._weights_key() != self.wkey):
+            return "the parameters changed (optimizer step / load) after its first pass"
+        return ""
 
     def fits(self, B: int, S: int) -> bool:
         return (not self.closed and self.placed < self.MAX_PASSES and self.row0[-1] + B * S <= self.T and
@@ -570,7 +639,10 @@ class StepArena:
         hd = rt.geom.hidden_size // rt.geom.num_attention_heads
         with torch.cuda.device(self.dev):
             rg, rl = rt._rope_tables(max(S, 64), self.dev, hd)
-            check(fn("snx_model_forward_range")(C.byref(rt._desc), rt._param_ptrs(), _p(rt._weights()), _p(ids_k), _p(mask_k),
+            wc = rt._weights()
+            if k == 0:
+                self.wkey = rt._wcache_key
+            check(fn("snx_model_forward_range")(C.byref(rt._desc), rt._param_ptrs(), _p(wc), _p(ids_k), _p(mask_k),
                                                 _p(cu), _p(pos), _p(rg), _p(rl), _p(self.saved), _p(self.sparse), _p(self.tw),
                                                 None, self.T, self.nseq, r0, s0, T, B, S, SNX_FWD_SAVE_FOR_BACKWARD,
                                                 _stream()), "snx_model_forward_range")
@@ -578,6 +650,8 @@ class StepArena:
         self.row0.append(r0 + T)
         self.seq0.append(s0 + B)
         self.grads.append(None)
+        self.nodes.append(None)
+        self.got.append(False)
         self.placed += 1
         return self.sparse[s0:s0 + B], self.tw[r0:r0 + T], self, k
 
@@ -593,16 +667,20 @@ class StepArena:
         """Backward of node k: hand in dL/d sparse_k.  Returns the parameter gradients from the LAST node to report
         (None in the flat-gradient mode, where the native backward accumulates in place)."""
         rt = self.rt
-        if not self.closed:
+        if not self.reporting:
+            self.reporting = True
+            was_open = not self.closed
             self.closed = True                               # no further pass can join; the engine tells us when it is done
             if rt._arena is self:
                 rt._arena = None
-            rt.step_arena_backward_begins()
+            if was_open:                                     # (an arena dropped as stale is no micro-step of the history)
+                rt.step_arena_backward_begins()
             torch.autograd.Variable._execution_engine.queue_callback(self._engine_done)
         self.grads[k] = g
+        self.got[k] = True
         self.reported += 1
         sync = rt.grad_sync if (rt.direct_grads and rt.grad_sync is not None) else None
-        if self.reported < self.placed:
+        if self.reported + self.dead() < self.placed:        # (a dead node never reports: zeros stand in for it)
             if sync is not None:
                 sync.claim_backward(token)                   # hands the token back; never the last one outstanding
             return None
@@ -612,6 +690,10 @@ class StepArena:
         rt, n = self.rt, self.placed
         self.done = True
         shapes = list(self.shapes)
+        missing = sum(1 for g in self.grads if g is None)
+        if missing:
+            rt._arena_note("zero_filled", f"{missing} of {n} placed passes took no part in the loss: zeros were "
+                           "back-propagated for them")
         T, nseq = self.row0[-1], self.seq0[-1]
         V = rt.geom.vocab_size
         parts = [g.to(torch.float32) if g is not None else torch.zeros((b, V), dtype=torch.float32, device=self.dev)
@@ -685,6 +767,7 @@ class _SpladeEncodeFn(torch.autograd.Function):
             placed = rt.step_arena_place(pairs[0][0], pairs[0][1])
             if placed is not None:                       # this pass went into the micro-step's shared arena
                 sparse, tw, ctx.arena, ctx.k = placed
+                ctx.arena.attach(ctx.k, ctx)
                 ctx.sync_token = rt.grad_sync.on_forward() if (rt.direct_grads and rt.grad_sync is not None) else None
                 ctx.mark_non_differentiable(tw)
                 ctx.rows, ctx.vocab = [sparse.shape[0]], sparse.shape[1]

@@ -9,8 +9,8 @@ ref:src/model/losses.py:14-301.  Differences:
     (ref:losses.py:276-294);
   * extension (not in the reference, config 4 of BASELINE.json): ``positive_repr`` may hold the
     all-gathered positives of every rank ([world*B, V]) together with ``label_offset=rank*B``;
-  * the KL-distillation branch (ref:losses.py:239-253) is never fed by the trainer
-    (ref:train_v33_ddp.py:353-360); it is kept for API completeness as a few torch ops.
+  * the KL-distillation branch (ref:losses.py:239-253; never fed by the trainer, ref:train_v33_ddp.py:353-360) is
+    part of the same device kernels: it reuses InfoNCE's V-chunked in-batch dots -- no vendor-library call on this path.
 """
 from __future__ import annotations
 
@@ -18,7 +18,6 @@ from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from snx.loss import splade_loss
 
@@ -63,22 +62,19 @@ class SPLADELossV33(nn.Module):
         else:
             k, neg2d = 1, negative_repr
         use_mm = self.lambda_margin_mse > 0 and teacher_pos_scores is not None and teacher_neg_scores is not None
-        hp = (self.temperature, lam_q, lam_d, lam_neg, self.lambda_margin_mse if use_mm else 0.0)
+        use_kd = self.lambda_kd > 0 and teacher_scores is not None          # inactive in the V33 trainer
+        hp = (self.temperature, lam_q, lam_d, lam_neg, self.lambda_margin_mse if use_mm else 0.0,
+              self.lambda_kd if use_kd else 0.0, self.kd_temperature)
         bf16_mm = torch.is_autocast_enabled()        # the reference's torch.mm runs in bf16 under autocast
         loss, sc = splade_loss(anchor_repr, positive_repr, neg2d, hp, k,
                                tpos=teacher_pos_scores if use_mm else None,
                                tneg=teacher_neg_scores if use_mm else None,
-                               label_off=int(kwargs.get("label_offset", 0)), bf16_mm=bf16_mm)
+                               label_off=int(kwargs.get("label_offset", 0)), bf16_mm=bf16_mm,
+                               tscores=teacher_scores if use_kd else None)
         zero = getattr(self, "_zero", None)               # one cached 0-d zero per device (no fill kernel per call)
         if zero is None or zero.device != sc.device:
             zero = self._zero = sc.new_zeros(())
-        kd_loss = zero
-        if self.lambda_kd > 0 and teacher_scores is not None:   # inactive in the V33 trainer
-            off = int(kwargs.get("label_offset", 0))
-            student = (anchor_repr @ positive_repr[off:off + B].t()) / self.kd_temperature
-            kd_loss = F.kl_div(F.log_softmax(student, dim=-1),
-                               F.softmax(teacher_scores / self.kd_temperature, dim=-1), reduction="batchmean")
-            loss = loss + self.lambda_kd * kd_loss
+        kd_loss = sc[8] if use_kd else zero
         with torch.no_grad():
             nz = sc[6:8]
             self._ema = 0.1 * nz if self._ema is None else torch.add(0.9 * self._ema, nz, alpha=0.1)

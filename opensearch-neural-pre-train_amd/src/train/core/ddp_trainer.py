@@ -264,18 +264,30 @@ def micro_step(model, loss_fn: SPLADELossV33, batch: dict, global_step: int, dev
     # the source of goldens g2) -- a parity / debugging mode, not a training configuration
     with autocast(device_type=device.type, dtype=torch.bfloat16,
                   enabled=nb and os.environ.get("SNX_PRECISION", "auto") != "fp32"):
+        # cross-GPU in-batch negatives (BASELINE config 4): the all-gather of the positive vectors goes to the EXCHANGE stream
+        # as soon as they exist -- in the reference's call pattern right after the positive pass, so that it runs under the
+        # negative pass; in the fused pass straight after the forward -- and only the loss waits for it
+        xneg = cross_gpu_negatives and sdist.active()
+        gather = sdist.all_gather_with_grad_async
+        if os.environ.get("SNX_GATHER_INLINE", "0") == "1":  # A/B and tests: the collective inline on the compute stream
+            gather = lambda x: sdist.PendingGather(sdist.all_gather_with_grad(x), None)   # noqa: E731
+        gathered = None
         if _fuse_passes(model):
             (anchor_repr, _), (positive_repr, _), (negative_repr, _) = unwrap(model).forward_many(
                 [(q_ids, q_mask), (p_ids, p_mask), (n_ids, n_mask)], lengths)
+            if xneg:
+                gathered = gather(positive_repr)
         else:
             anchor_repr, _ = model(q_ids, q_mask)
             positive_repr, _ = model(p_ids, p_mask)
+            if xneg:
+                gathered = gather(positive_repr)
             negative_repr, _ = model(n_ids, n_mask)
         if num_negatives > 1:
             negative_repr = negative_repr.view(anchor_repr.shape[0], num_negatives, -1)
         extra = {}
-        if cross_gpu_negatives and sdist.active():
-            positive_repr = sdist.all_gather_with_grad(positive_repr)
+        if gathered is not None:
+            positive_repr = gathered.wait()
             extra["label_offset"] = sdist.rank() * anchor_repr.shape[0]
         loss, loss_dict = loss_fn(anchor_repr=anchor_repr, positive_repr=positive_repr,
                                   negative_repr=negative_repr, global_step=global_step,

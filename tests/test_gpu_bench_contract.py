@@ -55,6 +55,9 @@ def test_bench_under_torchrun_one_rank_over_rccl():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and math.isfinite(d["config"]["final_loss"]) and 100.0 < d["value"] < 1e5
+    comm = d["comm"]                                      # what RCCL itself saw
+    assert comm["world_size"] == 1 and "nccl" in comm["backend"] and comm["ranks_counted"] == 1.0
+    assert comm["rank_checksum"] == comm["rank_checksum_expected"] == 0.0 and comm["rccl_version"][0].isdigit()
 
 
 @pytest.mark.gpu
@@ -79,6 +82,9 @@ def test_bench_launch_line_with_two_ranks_rehearsed_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert math.isfinite(d["config"]["final_loss"]) and d["value"] > 0
     assert "cpu_baseline" not in d                       # rank 0 at N = 1 only
+    comm = d["comm"]                                      # the communicator's own account: two ranks, checksum 0 + 1
+    assert comm["world_size"] == 2 and comm["ranks_counted"] == 2.0 and comm["rank_checksum"] == 1.0 == comm["rank_checksum_expected"]
+    assert len(comm["devices"]) == 2 and comm["backend"] == "gloo"
 
 
 @pytest.mark.gpu

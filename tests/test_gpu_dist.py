@@ -356,7 +356,7 @@ def test_two_ranks_share_one_gpu(dev, tmp_path):
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, (r, so[-1500:], se[-3000:])
     reps = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
-    assert all(len(rep["cases"]) == 4 for rep in reps)
+    assert all(len(rep["cases"]) == 6 for rep in reps)       # 4 exchange cases + the two gather-stream comparisons
     out = os.path.join(root, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_report.jsonl"), "a") as f:

@@ -159,6 +159,54 @@ def test_embed_ln_bwd(dev):
     assert torch.allclose(dw, wl.grad, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("T,H,V", [(9000, 768, 3000), (70000, 256, 500)])
+def test_embed_ln_bwd_skewed_ids(dev, T, H, V):
+    """real text is Zipfian -- [CLS] / [SEP] once per sequence, frequent tokens several percent of
+    the rows.  Ids with more than 64 tokens ("heavy") are ranked through an LDS bitmap and summed in two fixed levels
+    (32-token chunks, then the chunks in order) instead of one wave walking the whole list.  Checked against an fp64
+    index_add of the exact dx rows, for bit-reproducibility over two runs, and at the 64 / 65 boundary; T = 70,000 crosses
+    the 65,536-index bitmap window."""
+    ops = _ops()
+    pad = V - 1
+    g = torch.Generator().manual_seed(T)
+    E = torch.randn(V, H, generator=g).to(dev)
+    w = (1 + 0.2 * torch.randn(H, generator=g)).to(dev)
+    ids = torch.randint(20, V, (T,), generator=g)
+    r = torch.rand(T, generator=g)
+    ids[r < 0.30] = 5                                   # ~30 % of the rows
+    ids[(r >= 0.30) & (r < 0.33)] = 7                   # ~3 %
+    ids[(r >= 0.33) & (r < 0.36)] = pad                 # padding takes no part
+    free = (r >= 0.40).nonzero().view(-1)
+    ids[free[:64]] = 11                                 # exactly 64: the last light size
+    ids[free[64:129]] = 12                              # exactly 65: the first heavy size
+    assert int((ids == 11).sum()) == 64 and int((ids == 12).sum()) == 65
+    ids = ids.to(dev)
+    dh = torch.randn(T, H, generator=g).to(dev)
+    El, wl = E.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    emb = torch.nn.functional.embedding(ids, El, padding_idx=pad)
+    torch.nn.functional.layer_norm(emb, (H,), wl, None, 1e-5).backward(dh)
+    runs = []
+    for _ in range(2):
+        gE = torch.zeros_like(E)
+        dw = torch.zeros(H, device=dev)
+        ops.embed_ln_bwd(dh, ids, E, w, gE, dw, 1e-5, pad)
+        runs.append((gE, dw))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    gE = runs[0][0]
+    assert gE[pad].abs().max().item() == 0.0
+    # torch's embedding backward adds fp32 rows with atomics: compare against an fp64 reference built from ITS per-row dx
+    El64 = E.double().clone().requires_grad_(True)
+    emb64 = torch.nn.functional.embedding(ids, El64, padding_idx=pad)
+    torch.nn.functional.layer_norm(emb64, (H,), w.double(), None, 1e-5).backward(dh.double())
+    ref = El64.grad
+    scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-6)
+    n_id = torch.bincount(ids, minlength=V).clamp_min(1).double()[:, None]
+    # fp32 rows (1e-6 relative each) summed over n terms: error grows like sqrt(n) .. n ulps of the largest partial sum
+    assert ((gE.double() - ref).abs() / scale <= 3e-6 * n_id.sqrt() + 1e-6 * n_id * 0 + 2e-5).all(), \
+        float(((gE.double() - ref).abs() / scale).max())
+    assert torch.allclose(runs[0][1].double(), wl.grad.double(), rtol=2e-3, atol=2e-2)
+
+
 def test_rope(dev):
     from oracle import splade_oracle as O
     ops = _ops()

@@ -244,6 +244,62 @@ def test_topk_indices_exact_on_a_fixture_that_bites(dev, full):
     assert tk["equal"], tk
 
 
+def test_sparse_regime_support_and_topk(dev, full):
+    """The regime training lives in: a trained V33 model keeps ~54 vocabulary dimensions per
+    document active (ref:huggingface/v33/README.md:240-245), random init keeps all 50,000.  One scalar shift of the decoder
+    bias (the pooled logit of rank 55, averaged over the batch) puts the random-init model there without a hand-built
+    ladder.  In that regime the INDEX statement of the north star is the sparse vector's SUPPORT: every dimension the
+    oracle has active must be active here and vice versa, except where the oracle's logit lies within twice the measured
+    value error of the ReLU gate; top-k ranks are compared wherever both neighbour gaps exceed twice the error
+    (the tail of 50,000 near-Gaussian logits is spaced ~sigma / (rank * 4.6): only the first ranks can qualify -- the
+    fraction is reported, the ladder fixture above is the test that bites on ranks).  Forward + the routed backward run
+    on the sparse pattern (finite gradients; the gate zeroes every inactive entry)."""
+    from oracle import splade_oracle as O
+    cfg, params, model = full
+    ids, mask = O.synth_ids(4, 256, cfg, torch.Generator().manual_seed(779), ragged=True)
+    with torch.no_grad():
+        ref0, _ = O.splade_forward(params, cfg, ids, mask, "bf16")
+    shift = float(torch.topk(torch.expm1(ref0.double()), 55, dim=-1).values[:, -1].mean())
+    p2 = dict(params)
+    p2["model.decoder.bias"] = params["model.decoder.bias"] - shift
+    old = model.model.decoder.bias.detach().clone()
+    try:
+        with torch.no_grad():
+            model.model.decoder.bias.copy_(p2["model.decoder.bias"].to(dev))
+            ref, _ = O.splade_forward(p2, cfg, ids, mask, "bf16")
+        model.zero_grad(set_to_none=True)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            got, _ = model(ids.to(dev), mask.to(dev))
+        (got * torch.rand_like(got)).sum().backward()
+        finite = all(torch.isfinite(p_.grad).all() for p_ in model.parameters())
+        g_bias = model.model.decoder.bias.grad.detach().cpu()
+    finally:
+        with torch.no_grad():
+            model.model.decoder.bias.copy_(old)
+        model.zero_grad(set_to_none=True)
+    got = got.detach().cpu()
+    st = sparse_ulp_stats(got, ref)
+    active_ref, active_got = ref > 0, got > 0
+    n_ref = active_ref.sum(1).tolist()
+    err = max(st["max_abs"], 1e-3)
+    near_gate = torch.expm1(ref.double()).abs() <= 2 * err                 # |logit| within twice the error of the gate
+    # an entry the oracle gated off has no recoverable logit: it may appear here only with a value inside the error
+    flips = active_ref != active_got
+    bad = flips & ~(near_gate & active_ref) & ~(active_got & ~active_ref & (got.double() <= 2 * err))
+    k = max(8, min(min(n_ref), 48))
+    tk = topk_rank_check(got, ref, k, st["max_abs"])
+    _report("sparse_regime", {"bias_shift": -shift, "active_dims_oracle": n_ref, "active_dims_hip": active_got.sum(1).tolist(),
+                              "support_flips": int(flips.sum()), "support_flips_outside_the_gate_band": int(bad.sum()),
+                              "ulp": st, "topk_k": k, "topk": tk})
+    assert all(25 <= n <= 110 for n in n_ref), n_ref                        # the regime: tens of active dimensions, not 50,000
+    assert int(bad.sum()) == 0, int(bad.sum())
+    assert st["far"] == 0 and st["max_abs"] <= 8e-3, st
+    assert tk["equal"], tk
+    assert finite
+    # decoder.bias gradient lives only on active entries (the ReLU gate zeroes the rest)
+    assert int((g_bias != 0).sum()) <= int(active_got.any(0).sum())
+
+
 def test_full_size_values_ulp_statement(dev, full):
     """Forward only, 2 x 256 ragged tokens, default (near-flat) outputs: the ULP statement at full size."""
     from oracle import splade_oracle as O

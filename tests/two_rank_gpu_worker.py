@@ -107,6 +107,35 @@ def main(rank: int, port: int, outdir: str) -> None:
         report["cases"].append({"fused": fused, "mode": mode, "cross_gpu_negatives": xneg,
                                 "worst_avg_grad_err_rel_max": worst})
         del model, opt, sch
+    # ---- cross-GPU negatives: the all-gather on the exchange stream (issued right after the positive pass / the fused
+    # forward, only the loss waits for it) against the inline collective -- same values, same gradients, so after two
+    # optimizer steps the parameters must be BIT-equal (ordered reductions: two runs of one form are bit-equal too)
+    def run_xneg(fused: bool, inline: bool) -> torch.Tensor:
+        os.environ["SNX_FUSED_PASSES"] = "1" if fused else "0"
+        os.environ["SNX_GRAD_EXCHANGE"] = "allreduce"
+        os.environ["SNX_GATHER_INLINE"] = "1" if inline else "0"
+        model = T.NativeDataParallel(_build_model(cfg, mine, dev), n_buckets=3)
+        loss_fn = SPLADELossV33(temperature=20.0, flops_warmup_steps=4).to(dev)
+        opt = T.build_optimizer(model, conf)
+        sch = T.build_scheduler(opt, 0, 4)
+        step = 0
+        for i, b in enumerate(batches):
+            last = (i + 1) % 2 == 0
+            T.micro_step(model, loss_fn, b, step, dev, 2, cross_gpu_negatives=True, last_of_window=last)
+            if last:
+                T.optimizer_step(model, opt, sch, conf)
+                step += 1
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().reshape(-1) for p in model.module.parameters()]).clone()
+
+    for fused in (False, True):
+        a, b_ = run_xneg(fused, inline=True), run_xneg(fused, inline=False)
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b_), f"exchange-stream gather differs from the inline one (fused={fused}): " \
+                                   f"{float((a - b_).abs().max()):.3g}"
+        assert same_on_both_ranks(b_)
+        report["cases"].append({"fused": fused, "gather": "exchange stream == inline, bit for bit"})
+    os.environ.pop("SNX_GATHER_INLINE", None)
     dist.barrier()
     with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
         json.dump(report, f)

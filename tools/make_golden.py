@@ -18,7 +18,8 @@ reference source is copied.
 Fixtures: g1 tiny fwd/bwd (+g6 edge rows), g2 tiny train_epoch (1-proc and
 2-proc gloo DDP), g3 full-size fwd/bwd summaries, g4 loss-only vectors, g5 collator layout,
 g6 inference post-processing, g7 BASELINE config 5 (d512, k=4, MarginMSE) at full size, g8 the g3 batch
-with an unsaturated InfoNCE, g9 the loss's KL-distillation branch.
+with an unsaturated InfoNCE, g9 the loss's KL-distillation branch, g10 BASELINE config 1 as written (64 micro-steps of the
+149 M model through the reference's train_epoch).
 """
 from __future__ import annotations
 
@@ -532,6 +533,86 @@ def g9():
     np.savez_compressed(os.path.join(OUT, "g9_loss_kd.npz"), **arrs)
     json.dump(cases, open(os.path.join(OUT, "g9_loss_kd.json"), "w"), indent=1)
     print("g9 cases", len(cases), [c["loss_dict"]["kd"] for c in cases])
+
+
+def g10():
+    """BASELINE config 1 AS WRITTEN through the reference's own unmodified train_epoch (ref:train_v33_ddp.py:289-448):
+    ref:configs/train_v33.yaml loss / optimizer values (lambda_q 0.01, lambda_d 0.003, tau 1.0, FLOPS warm-up 20000, lr 5e-5,
+    wd 0.01, warm-up ratio 0.06, clip 1.0, accum 4, 25 epochs for the schedule's horizon), 1 process (gloo), fp32 CPU,
+    B = 4, 256 synthetic triplets (q <= 64 / d <= 256 ragged, SURVEY 8(d) generator seed 42) = 64 micro-steps = 16
+    optimizer steps, the 149 M model random-initialised by the SURVEY 2.2 recipe with seed 42.  Records the per-micro-step
+    loss and loss_dict, the update norm of all 137 tensors and update slices of probe tensors (the weights themselves:
+    597 MB, recreated from the recipe by the test).  ~8 minutes of CPU."""
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29633")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    T = _import_ref_trainer()
+    cfg = O.EncoderConfig()
+    params = O.init_params(cfg, seed=42)
+    torch.manual_seed(42)
+    model = build_reference_model(cfg, params)
+    init = {n: p.detach().clone() for n, p in model.named_parameters()}
+    ddp = T.DDP(model, broadcast_buffers=False, find_unused_parameters=False)
+    conf = T.V33Config()
+    import yaml
+    raw = yaml.safe_load(open(os.path.join(REF, "configs/train_v33.yaml")))
+    for k, v in raw["loss"].items():
+        setattr(conf.loss, k, v)
+    for k, v in raw["training"].items():
+        setattr(conf.training, k, v)
+    conf.data.batch_size = 4
+    loss_fn = T.SPLADELossV33(lambda_q=conf.loss.lambda_q, lambda_d=conf.loss.lambda_d, temperature=conf.loss.temperature,
+                              flops_warmup_steps=conf.loss.flops_warmup_steps, lambda_kd=conf.loss.lambda_kd,
+                              kd_temperature=conf.loss.kd_temperature, lambda_initial_ratio=conf.loss.lambda_initial_ratio,
+                              lambda_margin_mse=conf.loss.lambda_margin_mse, lambda_neg=conf.loss.lambda_neg)
+    rec = []
+    loss_fn.register_forward_hook(lambda m, i, o: rec.append((float(o[0].item()), dict(o[1]))))
+    no_decay = ["bias", "LayerNorm.weight", "layer_norm.weight"]
+    groups = [{"params": [p for n, p in ddp.named_parameters() if not any(nd in n for nd in no_decay)],
+               "weight_decay": conf.training.weight_decay},
+              {"params": [p for n, p in ddp.named_parameters() if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+    opt = T.AdamW(groups, lr=conf.training.learning_rate)
+    n_micro, accum = 64, conf.training.gradient_accumulation_steps
+    total_steps = (n_micro // accum) * conf.training.num_epochs          # ref:train_v33_ddp.py:584-586
+    warm = int(total_steps * conf.training.warmup_ratio)
+    sched = T.get_cosine_schedule_with_warmup(opt, num_warmup_steps=warm, num_training_steps=total_steps)
+    gen = torch.Generator().manual_seed(42)
+    batches = [O.synth_batch(4, 64, 256, cfg, gen, k=1, ragged=True) for _ in range(n_micro)]
+    ds = _Batches(batches)
+    sampler = T.DistributedSampler(ds, num_replicas=1, rank=0, shuffle=False)
+    dl = T.DataLoader(ds, batch_size=None, sampler=sampler)
+    t0 = time.time()
+    avg, gs = T.train_epoch(ddp, dl, loss_fn, opt, sched, conf, epoch=1, global_step=0, device=torch.device("cpu"),
+                            tb_logger=None)
+    wall = time.time() - t0
+    arrs = {"losses": np.array([r[0] for r in rec], dtype=np.float64)}
+    names, upd_norm, init_norm = [], [], []
+    for n, p in model.named_parameters():
+        u = p.detach().double() - init[n].double()
+        names.append(n)
+        upd_norm.append(float(u.norm()))
+        init_norm.append(float(init[n].double().norm()))
+    probes = ["model.model.embeddings.norm.weight", "model.model.layers.0.attn.Wqkv.weight",
+              "model.model.layers.10.mlp.Wi.weight", "model.model.layers.21.mlp.Wo.weight", "model.head.dense.weight",
+              "model.decoder.bias", "model.model.final_norm.weight"]
+    live = dict(model.named_parameters())
+    for n in probes:
+        u = (live[n].detach() - init[n])
+        arrs["uprobe::" + n] = np_(u[:8, :64] if u.dim() == 2 else u[:512])
+    np.savez_compressed(os.path.join(OUT, "g10_config1_train_epoch.npz"), **arrs)
+    json.dump({"conf": {"lr": conf.training.learning_rate, "wd": conf.training.weight_decay,
+                        "clip": conf.training.gradient_clip, "accum": accum, "warmup": warm, "total_steps": total_steps,
+                        "lambda_q": conf.loss.lambda_q, "lambda_d": conf.loss.lambda_d, "temperature": conf.loss.temperature,
+                        "flops_warmup_steps": conf.loss.flops_warmup_steps,
+                        "lambda_initial_ratio": conf.loss.lambda_initial_ratio, "batch": 4, "q_len": 64, "d_len": 256,
+                        "n_micro": n_micro, "batch_seed": 42, "init_seed": 42},
+               "avg_loss": avg, "global_step": gs, "dicts": [r[1] for r in rec], "param_names": names,
+               "update_norms": upd_norm, "init_norms": init_norm, "wall_s_cpu_fp32_8_threads": wall,
+               "transformers": __import__("transformers").__version__},
+              open(os.path.join(OUT, "g10_config1_train_epoch.json"), "w"), indent=1)
+    print("g10 global_step", gs, "avg", avg, "first losses", [r[0] for r in rec[:4]], "wall", wall)
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":
