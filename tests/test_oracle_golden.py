@@ -269,3 +269,33 @@ def test_g9_kd_branch_matches_reference():
         loss.backward()
         for x, t in zip("apn", (a, p, n)):
             np.testing.assert_allclose(t.grad.numpy(), z[pre + "d" + x], atol=2e-6, rtol=5e-4)
+
+
+def test_g10_config1_first_micro_step_reproduced_by_the_oracle(golden_dir):
+    """Golden g10 = BASELINE config 1 as written through the reference's own train_epoch (149 M, 64 micro-steps; the run
+    itself is replayed on the GPU by tests/test_gpu_config1.py).  Here, on the CPU: the fixture's recipe (init seed, batch
+    generator) rebuilt from its json gives the reference's first micro-step loss and terms through the ORACLE's fp32
+    forward -- the weights / batches the GPU test feeds are the ones the reference saw."""
+    import json
+    import os
+    import numpy as np
+    import torch
+    from oracle import splade_oracle as O
+    meta = json.load(open(os.path.join(golden_dir, "g10_config1_train_epoch.json")))
+    z = np.load(os.path.join(golden_dir, "g10_config1_train_epoch.npz"))
+    c = meta["conf"]
+    assert meta["global_step"] == 16 and len(z["losses"]) == c["n_micro"] == 64 and len(meta["param_names"]) == 137
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    cfg = O.EncoderConfig()
+    params = O.init_params(cfg, seed=c["init_seed"])
+    gen = torch.Generator().manual_seed(c["batch_seed"])
+    b = O.synth_batch(c["batch"], c["q_len"], c["d_len"], cfg, gen, k=1, ragged=True)
+    with torch.no_grad():
+        reps = [O.splade_forward(params, cfg, b[t + "_input_ids"], b[t + "_attention_mask"], "fp32")[0]
+                for t in ("query", "positive", "negative")]
+        lc = O.LossConfig(lambda_q=c["lambda_q"], lambda_d=c["lambda_d"], temperature=c["temperature"],
+                          flops_warmup_steps=c["flops_warmup_steps"], lambda_initial_ratio=c["lambda_initial_ratio"])
+        loss, d = O.loss_v33(lc, reps[0], reps[1], reps[2], 0, None, None, "fp32")
+    assert float(loss) == pytest.approx(float(z["losses"][0]), rel=1e-4)
+    for key in ("flops_q", "flops_d", "flops_neg"):
+        assert float(d[key]) == pytest.approx(meta["dicts"][0][key], rel=2e-5), key
