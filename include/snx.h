@@ -262,7 +262,9 @@ int snx_gemm_tn_accum_group(const snx_tn_problem* probs /*[host]*/, int32_t npro
  * launch's by fp32 summation order (each count is bit-reproducible by itself). */
 /* Process-wide switches of the library (csrc/config.h).  The library reads no environment variable; the Python binding
  * maps its SNX_* variables onto these keys once, at load time (snx/_lib.py), tests and tools call them directly.
- * Keys (default): nt256 (1; 0 off, 2 every eligible shape), nt256_min_m (8192), tn256 (1), tn256_min_m (8192),
+ * Keys (default): nt256 (1; 0 off, 2 every eligible shape), nt256_min_m (8192), nt256_coldeal (1: the 64-row units left
+ * over after the whole rounds of 256x256 tiles are dealt along column runs, one short tile per workgroup; 0: in tile order;
+ * same bits), tn256 (1), tn256_min_m (8192),
  * dec256 (1), dec256_min_t (2048), bwd_overlap (1), side_prio (1), attn_streaming (0), attn_bwd_onepass (1),
  * splade_dh_panels (16), f32_gemm64 (0), f32_attn_rows (0), wcache_per_tensor (0), resid_in_ln (1: the Wo GEMMs store
  * bf16 and the residual add happens inside the following LayerNorm; 0: in the GEMMs' fp32 epilogue, same bits),

@@ -8,6 +8,8 @@
 struct SnxConfig {
   int nt256 = 1;              // 256x256 persistent NT GEMM: 0 off, 1 default shape policy, 2 every eligible shape
   int nt256_min_m = 8192;     //   ... from this many rows on
+  int nt256_coldeal = 1;      //   ... leftover 64-row units dealt along column runs: one short tile per workgroup (0: in tile
+                              //   order, two short tiles for three workgroups in eight; A/B).  Same bits either way.
   int tn256 = 1;              // 256x256 persistent weight-gradient GEMM (0: the 128x128 kernel everywhere)
   int tn256_min_m = 8192;
   int dec256 = 1;             // 256x192 persistent decoder + SPLADE kernel (0: the 128x128 kernel)

@@ -12,6 +12,7 @@ struct Key { const char* name; int SnxConfig::*field; int lo, hi; };
 const Key KEYS[] = {
     {"nt256", &SnxConfig::nt256, 0, 2},
     {"nt256_min_m", &SnxConfig::nt256_min_m, 1, 1 << 30},
+    {"nt256_coldeal", &SnxConfig::nt256_coldeal, 0, 1},
     {"tn256", &SnxConfig::tn256, 0, 1},
     {"tn256_min_m", &SnxConfig::tn256_min_m, 1, 1 << 30},
     {"dec256", &SnxConfig::dec256, 0, 1},

@@ -25,7 +25,9 @@
 // Work split without a tail and without inter-workgroup traffic.  Every XCD owns a contiguous run of the tile
 // sequence (the XCD-aware column-group order of gemm_core.h); its 32 workgroups take the run's tiles interleaved,
 // whole rounds of 32 at a time, and the n mod 32 tiles left over are cut into UNITS of 64 rows x 256 columns dealt
-// contiguously: at most two SHORT tiles of 64, 128 or 192 rows per workgroup.  A short tile of 64 u rows keeps the
+// contiguously: at most two SHORT tiles of 64, 128 or 192 rows per workgroup (round 6: the units are dealt along the
+// leftover tiles' COLUMN runs, where a short tile may cross a row-panel boundary -- one short tile per workgroup instead
+// of two for three workgroups in eight; see next_tile).  A short tile of 64 u rows keeps the
 // LDS image and the schedule of a whole one: wave group g's rows [32 u g, 32 u (g + 1)) of the tile land in its
 // usual LDS rows (the DMA source rows are remapped, rows past 32 u re-read a valid row), the MFMAs of row tiles
 // that do not exist are skipped (phases of 16, 8 or 0 MFMAs), the write-back stops after u passes.  36,864 token
@@ -76,6 +78,7 @@ struct Work {
   int dbg;                           // diagnostics: 1 = no write-back, 2 = every tile reads operand tile (0, 0),
                                      // 4 = write-back without its global stores, 8 = stores drain at once (no vmcnt slack),
                                      // 16 = no deep request at tile boundaries
+  int coldeal;                       // leftover units dealt along COLUMN runs (round 6, see next_tile)
 };
 
 struct Tile { int m0, n0, u; };      // first row, first column, 64-row units (0: no tile)
@@ -134,6 +137,17 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
   int kround = 0;
   long x = 4 * (P0 + (long)nround * per) + 4L * nleft * jw / per;            // leftover units of this workgroup
   const long xe = 4 * (P0 + (long)nround * per) + 4L * nleft * (jw + 1) / per;
+  // Column-run dealing of the leftover units (wk.coldeal: one column group, the XCD's leftover tiles inside one
+  // super-block -- then position p of the super-block is (row panel p / tn, column tile p % tn)).  The nleft leftover tiles
+  // of the run, positions [pa, pb), hold in column c the CONTIGUOUS row panels first_c .. last_c; their units are listed
+  // column by column and every workgroup takes a contiguous piece of that list: a piece inside one column's run is ONE
+  // short tile of up to 4 units whose first row is any multiple of 64 (the tile's rows need not lie in one row panel).
+  // With the units dealt in tile order (above) a piece of 2.75 units straddled a tile boundary for three workgroups in
+  // eight, i.e. two short tiles = two latency-bound K loops.  Same outputs bit for bit: a tile's K loop does not depend on
+  // which rows share it.  The pieces of one column run side by side (workgroups jw, jw + 1, ...), the three columns at the
+  // same time: the A rows of a piece are shared through the XCD's L2 by the workgroups of the other columns.
+  int y = (int)(4L * nleft * jw / per);
+  const int ye = (int)(4L * nleft * (jw + 1) / per);
 
   auto next_tile = [&]() __attribute__((always_inline)) {                                  // u = 0: none
     Tile t;
@@ -143,6 +157,31 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
       tile_of(wk.order, (int)(P0 + (long)kround * per + jw), pm, pn);
       ++kround;
       t.m0 = pm * BM; t.n0 = pn * BN; t.u = 4;
+      return t;
+    }
+    if (wk.coldeal) {
+      if (y >= ye) return t;
+      const int tn = wk.order.tn, per_sb = wk.order.sb_rows * tn;
+      const long Pl = P0 + (long)nround * per;
+      const int sb = (int)(Pl / per_sb);
+      const int pa = (int)(Pl - (long)sb * per_sb), pb = pa + nleft;
+      int cum = 0;
+      for (int c = 0; c < tn; ++c) {
+        const int first = pa > c ? (pa - c + tn - 1) / tn : 0;
+        const int last = pb - 1 >= c ? (pb - 1 - c) / tn : -1;
+        const int cnt = last >= first ? last - first + 1 : 0;
+        if (y < cum + 4 * cnt) {
+          const int o = y - cum;
+          int uu = ye - y < 4 ? ye - y : 4;
+          uu = 4 * cnt - o < uu ? 4 * cnt - o : uu;
+          t.m0 = (sb * wk.order.sb_rows + first) * BM + 64 * o;
+          t.n0 = c * BN;
+          t.u = uu;
+          y += uu;
+          return t;
+        }
+        cum += 4 * cnt;
+      }
       return t;
     }
     if (x >= xe) return t;
@@ -592,6 +631,20 @@ static int launch(const void* A, const void* B, int M, int N, int K, const EpiAr
   wk.order = TileOrder{tm, tn, cdiv(tm, 8), cg};
   wk.units = 4L * tm * tn;
   wk.dbg = dbg;
+  // column-run dealing of the leftover units: needs position -> (p / tn, p % tn) inside a super-block, i.e. ONE column
+  // group, and every XCD's leftover tiles inside one super-block ("nt256_coldeal" = 0: the round-3 dealing, for A/B)
+  wk.coldeal = 0;
+  {
+    const int nwg_ = NWG - snx_get_reserved_cus(), per = nwg_ >> 3;
+    const long ntiles = (long)tm * tn, per_sb = (long)wk.order.sb_rows * tn;
+    bool ok = cg == tn && per > 0 && g_snx_cfg.nt256_coldeal != 0;
+    for (int xcd = 0; ok && xcd < 8; ++xcd) {
+      const long P0 = ntiles * xcd / 8, P1 = ntiles * (xcd + 1) / 8;
+      const long nround = (P1 - P0) / per, Pl = P0 + nround * per;
+      if (P1 > Pl && Pl / per_sb != (P1 - 1) / per_sb) ok = false;
+    }
+    wk.coldeal = ok ? 1 : 0;
+  }
   static bool attr[64] = {};
   int devid = 0;
   if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return SNX_E_ARG;

@@ -647,6 +647,40 @@ def test_gemm_nt256_all_epilogues_equal_the_128_kernel_bit_for_bit(dev, M, N, K)
         fn("snx_nt256_configure")(1, 8192)
 
 
+@pytest.mark.parametrize("M,N,K", [(36864, 768, 2304), (36864, 768, 768), (36864, 2304, 768), (20037, 768, 1152),
+                                   (9000, 512, 384), (33333, 1280, 320)])
+def test_gemm_nt256_column_run_dealing_of_the_leftover_units(dev, M, N, K):
+    """Round 6: the 64-row units left after the whole rounds of tiles are dealt along the leftover tiles' COLUMN runs (one
+    short tile per workgroup, its rows free to cross a row-panel boundary) instead of in tile order (two short tiles for
+    three workgroups in eight at N = 768).  A tile's K loop does not depend on which rows share it: plain store, RoPE and
+    GeGLU-forward outputs must equal the tile-order dealing's bit for bit (and, through the test above, the 128x128
+    kernel's)."""
+    from snx._lib import fn
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    x = torch.randn(M, K, generator=g).to(dev).to(BF16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(BF16)
+    tab = ops.rope_table(256, 64, 160000.0, dev)
+    pos = (torch.arange(M, dtype=torch.int32, device=dev) % 256).contiguous()
+    rows = ops.rope_rows(tab, pos)
+    rc = (2 * N // 3) // 64 * 64
+    calls = {"store": lambda: (ops.gemm_nt(x, w),), "rope_rows": lambda: (ops.gemm_nt_rope_rows(x, w, tab, pos, rows, rc),),
+             "geglu_fwd": lambda: ops.gemm_nt_geglu_fwd(x, w)}
+    try:
+        fn("snx_nt256_configure")(2, 1024)
+        for name, f in calls.items():
+            assert fn("snx_configure")(b"nt256_coldeal", 0) == 0
+            ref = [t.clone() for t in f()]
+            assert fn("snx_configure")(b"nt256_coldeal", 1) == 0
+            got = f()
+            torch.cuda.synchronize()
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b), (name, M, N, K, float((a.float() - b.float()).abs().max()))
+    finally:
+        fn("snx_configure")(b"nt256_coldeal", 1)
+        fn("snx_nt256_configure")(1, 8192)
+
+
 @pytest.mark.parametrize("M", [8192 + 64, 8192 + 37])
 def test_gemm_tn_256_layout(dev, M):
     """Exact check of the 256x256 form: dY = a 0/1 selection pattern, so dW[n, :] = X[row(n), :] bit for bit

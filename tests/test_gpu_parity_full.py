@@ -291,7 +291,8 @@ def test_sparse_regime_support_and_topk(dev, full):
     _report("sparse_regime", {"bias_shift": -shift, "active_dims_oracle": n_ref, "active_dims_hip": active_got.sum(1).tolist(),
                               "support_flips": int(flips.sum()), "support_flips_outside_the_gate_band": int(bad.sum()),
                               "ulp": st, "topk_k": k, "topk": tk})
-    assert all(25 <= n <= 110 for n in n_ref), n_ref                        # the regime: tens of active dimensions, not 50,000
+    # the regime: tens of active dimensions per document, not 50,000 (the batch is ragged: a 12-token document keeps fewer)
+    assert 25 <= sum(n_ref) / len(n_ref) <= 110 and all(4 <= n <= 200 for n in n_ref), n_ref
     assert int(bad.sum()) == 0, int(bad.sum())
     assert st["far"] == 0 and st["max_abs"] <= 8e-3, st
     assert tk["equal"], tk
