@@ -162,15 +162,18 @@ def test_config1_fp32_kernels_reproduce_the_references_run(dev, setup, golden):
         assert term_rel[key][0] <= (1e-4 if key == "infonce" else 5e-5), (key, term_rel[key])
     # after optimizer steps Adam turns gradients whose sign is rounding noise into +-lr steps; the loss is insensitive to
     # exactly those elements (their gradient is ~0), so the run stays on the reference's trajectory
-    assert rel.max() <= 2e-3, rep
+    # (measured round 6: 1.2e-5 on the loss, 2.6e-6 on the FLOPS terms over all 64 micro-steps)
+    assert rel.max() <= 2e-4, rep
     for key in ("flops_q", "flops_d", "flops_neg"):
-        assert term_rel[key][1] <= 2e-3, (key, term_rel[key])
+        assert term_rel[key][1] <= 5e-5, (key, term_rel[key])
     for i in range(64):
         for key in ("lambda_q", "lambda_d", "lambda_neg"):
             assert terms[i][key] == pytest.approx(meta["dicts"][i][key], rel=1e-12), (i, key)
-    assert avg == pytest.approx(meta["avg_loss"], rel=2e-3)
-    assert 0.9 <= min(ratios.values()) and max(ratios.values()) <= 1.1, rep["update_norm_ratio_minmax"]
-    assert min(probes.values()) >= 0.9, probes
+    assert avg == pytest.approx(meta["avg_loss"], rel=2e-4)
+    # every tensor's update after the 16 optimizer steps: norm within 1 % of the reference's (measured 0.9992 .. 1.0006), the
+    # probe slices' direction cos >= 0.999 (measured >= 0.99994)
+    assert 0.99 <= min(ratios.values()) and max(ratios.values()) <= 1.01, rep["update_norm_ratio_minmax"]
+    assert min(probes.values()) >= 0.999, probes
 
 
 @pytest.mark.parametrize("mode", ["plain", "three_call", "native"])
@@ -183,13 +186,14 @@ def test_config1_bf16_kernels_through_train_epoch(dev, setup, golden, mode):
     for key in ("flops_q", "flops_d", "flops_neg"):
         r = [abs(terms[i][key] - meta["dicts"][i][key]) / abs(meta["dicts"][i][key]) for i in range(64)]
         rel[key] = [max(r[:4]), max(r)]
-        assert rel[key][0] <= 1e-2, (key, rel[key])           # g3 protocol: bf16 kernels vs the reference's fp32 value
-        assert rel[key][1] <= 5e-2, (key, rel[key])           # ... and still on its trajectory after 16 optimizer steps
+        assert rel[key][0] <= 1e-3, (key, rel[key])           # bf16 kernels vs the reference's fp32 value (g3 protocol: 1e-2;
+        assert rel[key][1] <= 5e-3, (key, rel[key])           # measured 3e-5 in the first window, 2.4e-4 over the 16 optimizer steps)
     for i in range(64):
         for key in ("lambda_q", "lambda_d", "lambda_neg"):
             assert terms[i][key] == pytest.approx(meta["dicts"][i][key], rel=1e-12), (i, key)
     ratios, probes = _update_stats(final, setup[1], meta, z)
-    assert 0.7 <= min(ratios.values()) and max(ratios.values()) <= 1.4, (min(ratios.values()), max(ratios.values()))
+    assert 0.9 <= min(ratios.values()) and max(ratios.values()) <= 1.1, (min(ratios.values()), max(ratios.values()))
+    assert min(probes.values()) >= 0.9, probes            # (measured 0.97: bf16 gradients through Adam's sign-like first steps)
     inf = [abs(terms[i]["infonce"] - meta["dicts"][i]["infonce"]) for i in range(64)]
     _report(f"config1_bf16_{mode}_vs_reference_train_epoch_g10",
             {"flops_rel_err_first_window_and_max": rel, "infonce_abs_diff_max (saturated; reported)": max(inf),
