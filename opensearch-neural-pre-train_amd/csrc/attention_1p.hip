@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "attention_common.h"
+#include "config.h"
 #include "snx.h"
 
 namespace {
@@ -56,6 +57,7 @@ static_assert(8 * 8192 <= OFF_LSE, "epilogue staging (8 KiB per wave) overlays t
 struct Sched1p {
   int n;
   int seq0[SNX_ATTN_1P_GROUPS], bend[SNX_ATTN_1P_GROUPS];   // first sequence, exclusive prefix end of the group's units
+  int interleave;                                           // 1: the groups' units interleaved in proportion (round 6)
 };
 
 // Inside a plane a row is 32 bytes; rows 8..15 of every 16 swap their two 4-row groups and their two 16-byte halves,
@@ -108,11 +110,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  int g = 0, b0 = 0;
-#pragma unroll
-  for (int i = 0; i < SNX_ATTN_1P_GROUPS - 1; ++i)
-    if (i + 1 < sched.n && (int)blockIdx.x >= sched.bend[i]) { g = i + 1; b0 = sched.bend[i]; }
-  const int unit = (int)blockIdx.x - b0;
+  int g, unit;
+  block_to_group<SNX_ATTN_1P_GROUPS>(sched.bend, sched.n, sched.interleave, (int)blockIdx.x, g, unit);   // attention_common.h
   const int seq = sched.seq0[g] + unit / heads, head = unit % heads;
   const int s0 = cu_seqlens[seq];
   int slen = cu_seqlens[seq + 1] - s0;
@@ -471,6 +470,7 @@ int attn_bwd_onepass(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, c
     if (b > 0x7fffffffL) return SNX_E_SHAPE;
     sc.bend[i] = (int)b;
   }
+  sc.interleave = g_snx_cfg.attn_interleave != 0 && sc.n > 1;
   static LdsOptIn optin;
   if (const int rc = optin.ensure((const void*)attn_bwd_1p_kernel, LDS_1P)) return rc;
   hipLaunchKernelGGL(attn_bwd_1p_kernel, dim3((unsigned)b), dim3(512), LDS_1P, st, qkv, out, dout, lse, cu_seqlens, mask,

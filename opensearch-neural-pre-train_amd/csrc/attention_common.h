@@ -67,3 +67,34 @@ __device__ __forceinline__ void store_grad_rows(bf16_t* orow, const f32x4 (&acc)
   }
 }
 
+
+// Block -> (group, index inside the group) for launches that serve several sequence groups (e.g. the fused micro-step's
+// 64-token queries and 256-token documents).  `bend[i]` = exclusive prefix end of group i's blocks, n groups, NG = array
+// size.  interleave = 0: group by group (longest first, as the callers order them).  interleave = 1 (round 6): the groups'
+// blocks interleaved in proportion to their counts -- among the first b blocks of groups 0..i exactly floor(b n_i / N_i)
+// belong to group i (peeled from the last group) -- so that blocks of different length run side by side and the CUs
+// drift out of phase: in group-major order every CU is in its unit prologue (a burst of global loads with nothing else
+// resident to cover it) at the same time, HBM saturated for the burst and idle through the loops.  A bijection for any
+// counts; which block computes which unit changes no unit's arithmetic.
+template <int NG>
+__device__ __forceinline__ void block_to_group(const int (&bend)[NG], int n, int interleave, int b, int& g, int& idx) {
+  if (!interleave) {
+    g = 0;
+    int b0 = 0;
+#pragma unroll
+    for (int i = 0; i < NG - 1; ++i)
+      if (i + 1 < n && b >= bend[i]) { g = i + 1; b0 = bend[i]; }
+    idx = b - b0;
+    return;
+  }
+  g = 0;
+  idx = b;
+#pragma unroll
+  for (int i = NG - 1; i >= 1; --i) {
+    if (i >= n) continue;
+    const long ni = bend[i] - bend[i - 1], Ni = bend[i];
+    const int before = (int)((long)idx * ni / Ni), upto = (int)(((long)idx + 1) * ni / Ni);
+    if (upto > before) { g = i; idx = before; return; }
+    idx -= before;
+  }
+}

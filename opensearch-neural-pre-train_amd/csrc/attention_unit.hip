@@ -34,6 +34,7 @@ struct UnitSched {
   int n;
   int seq0[SNX_ATTN_UNIT_GROUPS], units[SNX_ATTN_UNIT_GROUPS], ntu[SNX_ATTN_UNIT_GROUPS];
   int bend[SNX_ATTN_UNIT_GROUPS];              // exclusive prefix end of the group's workgroups
+  int interleave;                              // 1: the groups' workgroups interleaved in proportion (attention_common.h)
 };
 
 struct Slot {
@@ -44,10 +45,8 @@ struct Slot {
 // RG = 16-row groups per wave (waves per unit = ntu * 4 / RG)
 template <int RG>
 __device__ __forceinline__ Slot slot_of_block(const UnitSched& sc, const int32_t* __restrict__ cu_seqlens, int heads) {
-  int g = 0, b0 = 0;
-#pragma unroll
-  for (int i = 0; i < SNX_ATTN_UNIT_GROUPS - 1; ++i)
-    if (i + 1 < sc.n && (int)blockIdx.x >= sc.bend[i]) { g = i + 1; b0 = sc.bend[i]; }
+  int g, bidx;
+  block_to_group<SNX_ATTN_UNIT_GROUPS>(sc.bend, sc.n, sc.interleave, (int)blockIdx.x, g, bidx);
   Slot t;
   t.ntu = sc.ntu[g];
   const int upb = NTMAX / t.ntu;
@@ -56,7 +55,7 @@ __device__ __forceinline__ Slot slot_of_block(const UnitSched& sc, const int32_t
   t.slot = wave / t.wpu;
   t.lw = wave - t.slot * t.wpu;
   t.lt = (int)threadIdx.x - t.slot * t.wpu * 64;
-  const int unit = ((int)blockIdx.x - b0) * upb + t.slot;
+  const int unit = bidx * upb + t.slot;
   t.live = t.slot < upb && unit < sc.units[g];
   const int seq = sc.seq0[g] + (t.live ? unit / heads : 0);
   t.head = t.live ? unit % heads : 0;
@@ -521,6 +520,7 @@ int build_unit_sched(UnitSched& sc, int& blocks, const int32_t* groups, int head
     sc.bend[i] = (int)b;
   }
   blocks = (int)b;
+  sc.interleave = g_snx_cfg.attn_interleave != 0 && sc.n > 1;
   return SNX_OK;
 }
 
