@@ -135,7 +135,3 @@ int snx_embed_ln_bwd_x(const float* dh, const int64_t* ids, const float* E, cons
                        int32_t T, int32_t H, int32_t V, float eps, int32_t pad_id, void* ws, size_t ws_bytes,
                        LnDwBatch* defer, int* ndefer, hipStream_t st);
 
-// routed decoder backward with its weight half (dE / db) on a second stream (splade_head.hip); st_dw == st: one stream
-int snx_splade_bwd_streams(const float* g, const uint32_t* keys, const void* Hd, const void* W, const int32_t* cu_seqlens,
-                           void* dHd, float* gradE, float* gradb, void* scratch, int32_t T, int32_t nseq, int32_t max_seqlen,
-                           int32_t V, int32_t H, hipStream_t st_dw, hipStream_t st);

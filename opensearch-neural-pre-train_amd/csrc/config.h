@@ -18,10 +18,9 @@ struct SnxConfig {
   int side_prio = 1;          //   ... which has the lowest stream priority
   int attn_streaming = 0;     // 1: tile-by-tile attention kernels for every sequence length
   int attn_bwd_onepass = 1;   // one-pass attention backward for sequences of <= 256 tokens (0: dQ + dK/dV pair)
-  int attn_interleave = 1;    // units of the sequence groups interleaved in proportion (0: group by group, longest first)
+  int attn_interleave = 0;    // 1: units of the sequence groups interleaved in proportion (attention_common.h); default 0 =
+                              // group by group, longest first -- measured level in the step (45.08 against 45.01 ms, ABAB)
   int splade_dh_panels = 16;  // vocabulary panels of the routed decoder backward's dHd gather (0: one wave per row)
-  int splade_bwd_split = 1;   // model backward: the routed decoder backward's weight half on the side stream, beside its
-                              // activation half (0: one stream, back to back; A/B).  Same kernels, same bits.
   int f32_gemm64 = 0;         // fp32 path: the 64x64 GEMM tile for every shape
   int f32_attn_rows = 0;      // fp32 path: wave-per-(token, head) attention forward
   int wcache_per_tensor = 0;  // bf16 weight cache refreshed one launch per tensor

@@ -547,14 +547,11 @@ extern "C" int snx_model_backward_units_range(const snx_model_desc* d, const voi
     char* A = sc + b.p[(L - 1) & 1];                  // d(mlp.Wo out) of the last layer ends up here
     // SPLADE tail + decoder (sparse routed), head
     { PROF(PC_SPLADE_BWD, 2.0 * 2.0 * nseq * V * H);
-      // the weight half (dE, db) on the side stream -- idle in this unit -- beside the activation half (bucket sort + dHd
-      // gather): two latency-bound gathers sharing the CUs' wave slots.  The side stream is in order: the marks of the
-      // layers' grouped launches (joined before the embedding unit, signalled to `notify`) cover it.
-      const bool split = overlap && g_snx_cfg.splade_bwd_split != 0;
-      if (split) RC(fork());
-      RC(snx_splade_bwd_streams(g_sparse, (const uint32_t*)(sv + s.keys), sv + s.hd, wc + c.emb, cu_seqlens, A,
-                                G(p.tok_emb()), G(p.dec_bias()), sc + b.splade, T, nseq, max_seqlen, V, H, split ? ss : st, st));
-      if (split) RC(mark(g_side.done[0])); }
+      // (round 6, measured and dropped: the weight half -- dE / db -- on the idle side stream beside the activation half:
+      // 45.23 against 45.01 ms per micro-step on one box, ABAB; two gathers that share the CUs' wave slots contend more
+      // than they hide)
+      RC(snx_splade_bwd(g_sparse, (const uint32_t*)(sv + s.keys), sv + s.hd, wc + c.emb, cu_seqlens, A, G(p.tok_emb()),
+                        G(p.dec_bias()), sc + b.splade, T, nseq, max_seqlen, V, H, st)); }
     { PROF(PC_LN_BWD, TH * 6); RC(snx_gelu_ln_bwd_x(A, sv + s.dd, F(p.head_norm()), Bb, G(p.head_norm()), T, H, d->ln_eps, LNWS(0), st)); }
     { PROF(PC_GEMM_TN, 2.0 * TH * H);
       RC(snx_gemm_tn_accum(Bb, sv + s.xf, G(p.head_dense()), T, H, H, sc + b.tnws_main, b.tnws_main_bytes, st)); }

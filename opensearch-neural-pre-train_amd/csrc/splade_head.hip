@@ -682,30 +682,14 @@ extern "C" size_t snx_splade_bwd_scratch_bytes(int32_t nseq, int32_t max_seqlen,
 extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* Hd, const void* W,
                               const int32_t* cu_seqlens, void* dHd, float* gradE, float* gradb, void* scratch,
                               int32_t T, int32_t nseq, int32_t max_seqlen, int32_t V, int32_t H, hipStream_t st) {
-  return snx_splade_bwd_streams(g, keys, Hd, W, cu_seqlens, dHd, gradE, gradb, scratch, T, nseq, max_seqlen, V, H, st, st);
-}
-
-// The two halves of the routed backward are independent: the weight half (dE / db: splade_bwd_dw_kernel, gathers of Hd rows
-// out of the XCDs' L2) and the activation half (bucket sort + dHd gather of W_E rows out of the Infinity Cache).  With
-// st_dw != st (the model's backward: its weight-gradient side stream, idle during the tail unit) the weight half runs on
-// st_dw -- which the CALLER has ordered behind the producers of g / keys / Hd and joins before gradE / gradb are consumed
-// -- beside the activation half: two latency-bound gathers that stall on different levels of the memory system share the
-// CUs' wave slots instead of running back to back.  Same kernels, same results.
-int snx_splade_bwd_streams(const float* g, const uint32_t* keys, const void* Hd, const void* W,
-                           const int32_t* cu_seqlens, void* dHd, float* gradE, float* gradb, void* scratch,
-                           int32_t T, int32_t nseq, int32_t max_seqlen, int32_t V, int32_t H, hipStream_t st_dw,
-                           hipStream_t st) {
   if (!g || !keys || !Hd || !W || !cu_seqlens || !dHd || !gradE || !gradb || !scratch) return SNX_E_ARG;
   if (T <= 0 || nseq <= 0 || V <= 0 || max_seqlen <= 0 || H <= 0 || (H % 256) || H > 1024) return SNX_E_SHAPE;
   const int blocks = cdiv(V, 32);               // 4 waves x 8 vocab rows per workgroup
-  {
-    hipStream_t st = st_dw;                     // (the launches below name `st`)
   switch (H / 256) {
     case 1: hipLaunchKernelGGL(splade_bwd_dw_kernel<1>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
     case 2: hipLaunchKernelGGL(splade_bwd_dw_kernel<2>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
     case 3: hipLaunchKernelGGL(splade_bwd_dw_kernel<3>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
     default: hipLaunchKernelGGL(splade_bwd_dw_kernel<4>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
-  }
   }
   SNX_CHECK_LAUNCH();
   // dHd: bucket by row, then one wave per token row

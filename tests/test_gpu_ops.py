@@ -942,6 +942,20 @@ def test_attention_sequence_groups_only_size_the_launch(dev, window):
     d0 = ops.attn_bwd(qkv, out0, dout, lse0, cu, mask, 256, heads, window)
     d1 = ops.attn_bwd(qkv, out0, dout, lse0, cu, mask, 256, heads, window, groups=groups)
     assert torch.equal(d0, d1)
+    # "attn_interleave" = 1 (round 6, opt-in): the groups' blocks interleaved in proportion to their counts instead of group
+    # by group -- another block -> unit bijection, the same units: bit-identical outputs (one-pass and two-pass backward)
+    import snx
+    try:
+        snx.configure(attn_interleave=1)
+        out2, lse2 = ops.attn_fwd(qkv, cu, mask, 256, heads, window, groups=groups)
+        d2 = ops.attn_bwd(qkv, out0, dout, lse0, cu, mask, 256, heads, window, groups=groups)
+        snx.configure(attn_bwd_onepass=0)
+        d3 = ops.attn_bwd(qkv, out0, dout, lse0, cu, mask, 256, heads, window, groups=groups)
+        snx.configure(attn_interleave=0)
+        d4 = ops.attn_bwd(qkv, out0, dout, lse0, cu, mask, 256, heads, window, groups=groups)
+    finally:
+        snx.configure(attn_interleave=0, attn_bwd_onepass=1)
+    assert torch.equal(out0, out2) and torch.equal(lse0, lse2) and torch.equal(d0, d2) and torch.equal(d3, d4)
     for bad in ([(0, 7, 64), (8, 4, 256), (11, 3, 100)],      # gap
                 [(0, 7, 64), (7, 4, 256)],                      # does not cover all sequences
                 [(0, 14, 300)],                                 # max_len above max_seqlen
