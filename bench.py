@@ -187,6 +187,9 @@ def main():
                     help="skip the extra leg that times the reference's literal loop (three forwards + loss.item())")
     ap.add_argument("--no-sparse-regime-leg", action="store_true",
                     help="skip the extra leg that times the step with a trained model's output sparsity")
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the extra legs that time BASELINE configs 5 (d512, 4 negatives, MarginMSE) and, at N > 1, "
+                         "4 (cross-GPU in-batch negatives) beside the headline configuration")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="time the CPU oracle sample and exit (no GPU)")
     ap.add_argument("--cpu-cores", default=None, help="threads of the CPU sample: a number, or 'all' (physical cores)")
     args = ap.parse_args()
@@ -496,6 +499,71 @@ def main():
                        "document stay active (the trained model's regime, ref:huggingface/v33/README.md:240-245) instead of "
                        "all 50,000 (random init, the headline's worst case for the arg-max-routed decoder backward)")
         result.setdefault("extra", {})["sparse_regime"] = leg
+
+    # ---- BASELINE configs 4 and 5 beside the headline (config 2 / 3), so that the driver's record carries them ----
+    # Only when the headline IS config 2 / 3 (the defaults): a run that was asked for another shape reports that shape alone.
+    default_shape = (B, Sq, Sd, k) == (64, 64, 256, 1) and args.margin_mse == 0.0 and not xneg
+    if default_shape and not args.no_config_legs:
+        def timed_leg(leg_batches, leg_loss, leg_xneg, nsteps):
+            st = {"i": 0}
+
+            def step():
+                bb = leg_batches[st["i"] % len(leg_batches)]
+                T.micro_step(wrapped, leg_loss, bb, state["gs"], dev, args.accum, leg_xneg,
+                             last_of_window=(st["i"] + 1) % args.accum == 0)
+                st["i"] += 1
+                if st["i"] % args.accum == 0:
+                    T.optimizer_step(wrapped, optimizer, scheduler, config)
+                    state["gs"] += 1
+            wrapped.zero_grad()
+            for _ in range(args.accum):
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
+                step()
+            barrier()
+            d = time.perf_counter() - t0
+            if use_pg:
+                tm = torch.tensor([d], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                d = float(tm.item())
+            return d
+        legs = result.setdefault("extra", {})
+        # Every rank takes the same branches below (the conditions are rank-independent), so the collectives inside the
+        # legs stay matched; an exception inside a leg is recorded instead of costing the run its headline line.
+        if backend == "nccl":                                # (two rehearsal ranks on ONE device would not fit two config-5 arenas)
+            # config 5: q64 / d512, 4 negatives per query, MarginMSE 0.5 with synthetic teacher scores (2,624 tokens per triplet)
+            try:
+                k5, sd5 = 4, 512
+                b5 = make_batches(4, B, Sq, sd5, k5, model.vocab_size, model.config.pad_token_id, 4242 + rank, dev, teacher=True)
+                loss5 = SPLADELossV33(lambda_q=config.loss.lambda_q, lambda_d=config.loss.lambda_d,
+                                      temperature=config.loss.temperature, flops_warmup_steps=config.loss.flops_warmup_steps,
+                                      lambda_initial_ratio=config.loss.lambda_initial_ratio, lambda_margin_mse=0.5).to(dev)
+                n5 = 2 * args.accum
+                d5 = timed_leg(b5, loss5, False, n5)
+                fl5 = flops_per_triplet(Sq, sd5, k5)
+                v5 = n5 * B * world / d5
+                legs["config5"] = {"workload": f"bs={B}/GPU, q{Sq}/d{sd5}, {k5} neg, InfoNCE+FLOPS+MarginMSE 0.5, "
+                                               f"grad-accum {args.accum}",
+                                   "value": v5, "unit": "triplets/s", "ms_per_step": 1000.0 * d5 / n5, "steps": n5,
+                                   "mfma_roofline_frac_step": v5 * fl5["step"] / (world * PEAK_BF16_TFLOPS * 1e12),
+                                   "mfma_roofline_frac_executed": v5 * fl5["step_executed"] / (world * PEAK_BF16_TFLOPS * 1e12)}
+                del b5
+            except Exception as e:                                  # noqa: BLE001
+                legs["config5"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+        if world > 1:
+            # config 4: config 3 + the all-gather of the positive vectors (exchange stream) / reduce-scatter backward
+            try:
+                n4 = 2 * args.accum
+                d4 = timed_leg(batches, loss_fn, True, n4)
+                legs["config4"] = {"workload": f"bs={B}/GPU, q{Sq}/d{Sd}, {k} neg, cross-GPU in-batch negatives "
+                                               f"({world * B} positives per anchor row)",
+                                   "value": n4 * B * world / d4, "unit": "triplets/s", "ms_per_step": 1000.0 * d4 / n4,
+                                   "steps": n4}
+            except Exception as e:                                  # noqa: BLE001
+                legs["config4"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()

@@ -35,6 +35,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert "no per-micro-step loss.item()" in d["config"]["workload"]
     ex = d["extra"]                                       # the reference's literal loop: three forwards + loss.item()
     assert 100.0 < ex["value_with_item_sync"] <= d["value"] * 1.05 and ex["steps"] >= 4
+    sp = ex["sparse_regime"]                              # the trained model's output sparsity: tens of active dimensions
+    assert 20.0 < sp["active_dims_doc"] < 120.0 and sp["active_dims_query"] < sp["active_dims_doc"] and sp["ms_per_step"] > 0
+    c5 = ex["config5"]                                    # BASELINE config 5 beside the headline
+    assert "error" not in c5 and 10.0 < c5["value"] < d["value"] and 0.05 < c5["mfma_roofline_frac_step"] < 1.0
+    assert "config4" not in ex                            # N > 1 only
     assert roof["traffic_provenance"]["status"].split(":")[0] in ("current", "stale", "absent")
     assert (roof["traffic"] is None) == (roof["traffic_provenance"]["status"] != "current")
 
@@ -85,6 +90,9 @@ def test_bench_launch_line_with_two_ranks_rehearsed_on_one_gpu():
     comm = d["comm"]                                      # the communicator's own account: two ranks, checksum 0 + 1
     assert comm["world_size"] == 2 and comm["ranks_counted"] == 2.0 and comm["rank_checksum"] == 1.0 == comm["rank_checksum_expected"]
     assert len(comm["devices"]) == 2 and comm["backend"] == "gloo"
+    c4 = d["extra"]["config4"]                           # BASELINE config 4's leg ran on both ranks (gathered positives: 128)
+    assert "error" not in c4 and c4["value"] > 0 and "128 positives" in c4["workload"]
+    assert "config5" not in d["extra"]                   # (nccl runs only: two rehearsal ranks share ONE device's memory)
 
 
 @pytest.mark.gpu
