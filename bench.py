@@ -140,7 +140,7 @@ def kernel_source_hash() -> str:
     return h.hexdigest()
 
 
-PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")
 
 
 def pmc_traffic(cls: str):

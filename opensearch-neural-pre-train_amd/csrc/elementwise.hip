@@ -153,6 +153,23 @@ struct RowVec {
 #pragma unroll
     for (int i = 0; i < NV; ++i) *(f32x4*)(p + (i * 64 + lane) * 4) = v[i];
   }
+  // non-temporal forms ("stream_nt", config.h): rows that are read for the last time / written for a reader tens of
+  // milliseconds away should not displace the next GEMM's operands from the L2 and the Infinity Cache
+  __device__ __forceinline__ void load_f32_nt(const float* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = __builtin_nontemporal_load((const f32x4*)(p + (i * 64 + lane) * 4));
+  }
+  __device__ __forceinline__ void load_bf16_nt(const bf16_t* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bf16x4 b = __builtin_nontemporal_load((const bf16x4*)(p + (i * 64 + lane) * 4));
+      v[i] = (f32x4){bf2f(b[0]), bf2f(b[1]), bf2f(b[2]), bf2f(b[3])};
+    }
+  }
+  __device__ __forceinline__ void store_f32_nt(float* p, int lane) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) __builtin_nontemporal_store(v[i], (f32x4*)(p + (i * 64 + lane) * 4));
+  }
   __device__ __forceinline__ void store_bf16(bf16_t* p, int lane) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -191,12 +208,15 @@ __device__ __forceinline__ float ln_normalize(RowVec<NV>& x, int H, float eps) {
 // MODE 2: src = gelu(bf16 d) evaluated on the bf16 tensor (head: LN(gelu(dense))).
 // MODE 3: src = h fp32 + bf16 d (the residual add of hf:331-332 done HERE: a Linear's bf16 output joins the fp32 stream),
 //         also writes the sum to h_out -- what the residual epilogue of the Wo GEMMs computes, bit for bit.
-template <int NV, int MODE>
+// NT: "stream_nt" bits, compile-time (a run-time branch between a plain and a non-temporal load of the same address is
+// merged back into the plain one by the compiler)
+template <int NV, int MODE, int NT = 0>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h, const int64_t* __restrict__ ids,
                                                      const float* __restrict__ E, const bf16_t* __restrict__ d,
                                                      const float* __restrict__ w, float* __restrict__ h_out,
                                                      bf16_t* __restrict__ x_out, bf16_t* __restrict__ x0_out,
                                                      int T, int H, float eps) {
+  constexpr int nt = NT;
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (t >= T) return;
@@ -207,11 +227,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h
     x.load_f32(E + ids[t] * (long)H, lane);
   } else if (MODE == 3) {
     RowVec<NV> y;
-    x.load_f32(h + (long)t * H, lane);
-    y.load_bf16(d + (long)t * H, lane);
+    if (nt & 1) {                                 // h and y: their last read of the forward
+      x.load_f32_nt(h + (long)t * H, lane);
+      y.load_bf16_nt(d + (long)t * H, lane);
+    } else {
+      x.load_f32(h + (long)t * H, lane);
+      y.load_bf16(d + (long)t * H, lane);
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) x.v[i] += y.v[i];
-    x.store_f32(h_out + (long)t * H, lane);
+    if (nt & 2) x.store_f32_nt(h_out + (long)t * H, lane);   // next read: the following LayerNorm, then the backward
+    else x.store_f32(h_out + (long)t * H, lane);
   } else {
     x.load_bf16(d + (long)t * H, lane);
 #pragma unroll
@@ -256,8 +282,16 @@ extern "C" int snx_ln_fwd_add(const float* h, const void* y, const float* w, flo
                               int32_t H, float eps, hipStream_t st) {
   if (!h || !y || !w || !h_out || !x_out || T <= 0) return SNX_E_ARG;
   if (bad_h(H)) return SNX_E_SHAPE;
-  DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<NV, 3>), dim3(cdiv(T, ROWS_PER_BLOCK)), dim3(256), 0, st, h,
-                                    nullptr, nullptr, (const bf16_t*)y, w, h_out, (bf16_t*)x_out, nullptr, T, H, eps));
+  switch (g_snx_cfg.stream_nt & 3) {
+    case 1: DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<NV, 3, 1>), dim3(cdiv(T, ROWS_PER_BLOCK)), dim3(256), 0, st, h,
+                                    nullptr, nullptr, (const bf16_t*)y, w, h_out, (bf16_t*)x_out, nullptr, T, H, eps)); break;
+    case 2: DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<NV, 3, 2>), dim3(cdiv(T, ROWS_PER_BLOCK)), dim3(256), 0, st, h,
+                                    nullptr, nullptr, (const bf16_t*)y, w, h_out, (bf16_t*)x_out, nullptr, T, H, eps)); break;
+    case 3: DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<NV, 3, 3>), dim3(cdiv(T, ROWS_PER_BLOCK)), dim3(256), 0, st, h,
+                                    nullptr, nullptr, (const bf16_t*)y, w, h_out, (bf16_t*)x_out, nullptr, T, H, eps)); break;
+    default: DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<NV, 3>), dim3(cdiv(T, ROWS_PER_BLOCK)), dim3(256), 0, st, h,
+                                    nullptr, nullptr, (const bf16_t*)y, w, h_out, (bf16_t*)x_out, nullptr, T, H, eps)); break;
+  }
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }
@@ -296,7 +330,7 @@ extern "C" int snx_gelu_ln_fwd(const void* d, const float* w, void* x_out, int32
 //   MODE 2: input gelu(bf16 d); dd[t] = bf16(bf16(dx) * gelu'(d))          (head LN)
 //   MODE 3: input h fp32;   dh[t]  = dx  (overwrite: the final_norm, first op of backward)
 // ------------------------------------------------------------------------------------------
-template <int NV, int MODE>
+template <int NV, int MODE, int NT = 0>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ dyf,
                                                      const float* __restrict__ h, const int64_t* __restrict__ ids,
                                                      const float* __restrict__ E, const bf16_t* __restrict__ d,
@@ -305,6 +339,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      float* __restrict__ gradE, bf16_t* __restrict__ dd,
                                                      float* __restrict__ dw, float* __restrict__ dw_part, int T,
                                                      int H, float eps, int rows_per_block, int pad_id) {
+  constexpr int nt = NT;
   __shared__ float red[ROWS_PER_BLOCK][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   RowVec<NV> wv, dwacc;
@@ -317,7 +352,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     RowVec<NV> x, g, raw;
     long id = 0;
     if (MODE == 0 || MODE == 3) {
-      x.load_f32(h + (long)t * H, lane);
+      if (nt & 4) x.load_f32_nt(h + (long)t * H, lane);   // the saved residual row: read for the last time
+      else x.load_f32(h + (long)t * H, lane);
     } else if (MODE == 1) {
       id = ids[t];
       x.load_f32(E + id * (long)H, lane);
@@ -330,6 +366,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
     const float rstd = ln_normalize<NV>(x, H, eps);     // x = xhat
     if (MODE == 1) g.load_f32(dyf + (long)t * H, lane); // grad wrt embeddings output is the fp32 dh stream
+    else if (nt & 4) g.load_bf16_nt(dy + (long)t * H, lane);
     else g.load_bf16(dy + (long)t * H, lane);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -725,15 +762,17 @@ int snx_ln_bwd_x(const void* dy, const float* h, const float* w, float* dh, void
   const int rpb = ln_bwd_rows_per_block(T);
   const int nb = cdiv(T, rpb);
   LN_WS(snx_ln_bwd_workspace_bytes(T, H));
+#define SNX_LN_BWD_LAUNCH(MODE_, NT_)                                                                              \
+  DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, MODE_, NT_>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, \
+                                    nullptr, h, nullptr, nullptr, nullptr, w, dh, (bf16_t*)dh_bf16, nullptr, nullptr, \
+                                    dw, part, T, H, eps, rpb, -1))
+  const bool nt = (g_snx_cfg.stream_nt & 4) != 0;
   if (overwrite) {
-    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 3>), dim3(nb), dim3(256), 0, st,
-                                      (const bf16_t*)dy, nullptr, h, nullptr, nullptr, nullptr, w, dh,
-                                      (bf16_t*)dh_bf16, nullptr, nullptr, dw, part, T, H, eps, rpb, -1));
+    if (nt) { SNX_LN_BWD_LAUNCH(3, 4); } else { SNX_LN_BWD_LAUNCH(3, 0); }
   } else {
-    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, 0>), dim3(nb), dim3(256), 0, st,
-                                      (const bf16_t*)dy, nullptr, h, nullptr, nullptr, nullptr, w, dh,
-                                      (bf16_t*)dh_bf16, nullptr, nullptr, dw, part, T, H, eps, rpb, -1));
+    if (nt) { SNX_LN_BWD_LAUNCH(0, 4); } else { SNX_LN_BWD_LAUNCH(0, 0); }
   }
+#undef SNX_LN_BWD_LAUNCH
   SNX_CHECK_LAUNCH();
   return part ? ln_dw_finish(part, dw, nb, H, st, defer, ndefer) : SNX_OK;
 }

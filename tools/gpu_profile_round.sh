@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile set (run on the GPU box through gpurun; summaries are copied into profiles/ afterwards):
 #   bench JSON (config 2 and config 5), rocprofv3 kernel stats of the same command, PMC fabric traffic (two passes).
-R=${1:-r05}
+R=${1:-r06}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/prof_$R
