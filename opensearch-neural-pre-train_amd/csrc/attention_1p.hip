@@ -100,12 +100,18 @@ __device__ unsigned long long* g_attn1p_trace = nullptr;
 #define ATRACE_RT(k)
 #endif
 
+// NTL ("stream_nt" bit 32): q, k, v and dO are read for the last time here (the attention output O is read again by the
+// layer's weight-gradient GEMM): non-temporal loads keep them from displacing the following GEMMs' operands in the caches.
+template <bool NTL>
 __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, const int32_t* __restrict__ cu_seqlens, const int64_t* __restrict__ mask,
     bf16_t* __restrict__ dqkv, const f32x2* __restrict__ rope_tab, const int32_t* __restrict__ pos, int T, int heads,
     int window, float scale, const Sched1p sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  auto ld8 = [](const bf16_t* p) __attribute__((always_inline)) {
+    return NTL ? __builtin_nontemporal_load((const bf16x8*)p) : *(const bf16x8*)p;
+  };
   ATRACE(0); ATRACE_RT(12);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,8 +149,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
   bf16x8 qreg, doreg, oreg, kv[4], vb[4];
   {
     const int gr = srow < slen ? srow : slen - 1;
-    qreg = *(const bf16x8*)(qbase + (long)gr * rs + schunk * 8);
-    doreg = *(const bf16x8*)(dobase + (long)gr * H + schunk * 8);
+    qreg = ld8(qbase + (long)gr * rs + schunk * 8);
+    doreg = ld8(dobase + (long)gr * H + schunk * 8);
     oreg = *(const bf16x8*)(obase + (long)gr * H + schunk * 8);
   }
   const int nk64 = (slen + 63) >> 6;                         // 64-row blocks of K that hold keys (a 64-token query: one)
@@ -152,12 +158,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
   for (int i = 0; i < 4; ++i) {
     const int row = srow + 64 * i;
     const int gr = row < slen ? row : slen - 1;
-    if (i < nk64) kv[i] = *(const bf16x8*)(qbase + H + (long)gr * rs + schunk * 8);      // workgroup-uniform
+    if (i < nk64) kv[i] = ld8(qbase + H + (long)gr * rs + schunk * 8);      // workgroup-uniform
   }
   const bool has_keys = 32 * w < slen;                        // wave-uniform: this wave owns keys of the sequence
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
-    if (has_keys) vb[ks] = *(const bf16x8*)(qbase + 2 * H + (long)keyr * rs + 16 * ks + 8 * h);
+    if (has_keys) vb[ks] = ld8(qbase + 2 * H + (long)keyr * rs + 16 * ks + 8 * h);
   const int64_t mk = mask[s0 + keyr];
   float lse_t = 0.f;
   int pos_t = 0;
@@ -230,8 +236,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
     if (sl + 1 < nsl) {                                        // next slice: in flight during this one
       const int row = q0 + QS + srow;
       const int gr = row < slen ? row : slen - 1;
-      qreg = *(const bf16x8*)(qbase + (long)gr * rs + schunk * 8);
-      doreg = *(const bf16x8*)(dobase + (long)gr * H + schunk * 8);
+      qreg = ld8(qbase + (long)gr * rs + schunk * 8);
+      doreg = ld8(dobase + (long)gr * H + schunk * 8);
       oreg = *(const bf16x8*)(obase + (long)gr * H + schunk * 8);
     }
     WG_BARRIER();
@@ -471,9 +477,11 @@ int attn_bwd_onepass(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, c
     sc.bend[i] = (int)b;
   }
   sc.interleave = g_snx_cfg.attn_interleave != 0 && sc.n > 1;
-  static LdsOptIn optin;
-  if (const int rc = optin.ensure((const void*)attn_bwd_1p_kernel, LDS_1P)) return rc;
-  hipLaunchKernelGGL(attn_bwd_1p_kernel, dim3((unsigned)b), dim3(512), LDS_1P, st, qkv, out, dout, lse, cu_seqlens, mask,
+  static LdsOptIn optin[2];
+  const bool ntl = (g_snx_cfg.stream_nt & 32) != 0;
+  auto kern = ntl ? attn_bwd_1p_kernel<true> : attn_bwd_1p_kernel<false>;
+  if (const int rc = optin[ntl ? 1 : 0].ensure((const void*)kern, LDS_1P)) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)b), dim3(512), LDS_1P, st, qkv, out, dout, lse, cu_seqlens, mask,
                      dqkv, rope_tab, pos, T, heads, window, 0.125f, sc);
   SNX_CHECK_LAUNCH();
   return SNX_OK;

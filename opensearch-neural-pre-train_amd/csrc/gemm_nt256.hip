@@ -114,7 +114,10 @@ struct IC { static constexpr int value = N; };
 
 }  // namespace
 
-template <int EPI>
+// NTU ("stream_nt" bit 8, GeGLU forward only): the saved u = [a | g] leaves through non-temporal stores -- its next reader
+// is the backward, tens of milliseconds away; as plain stores its 170 MB per launch displace the next GEMMs' operands
+// from the L2 / Infinity Cache (y, which the next GEMM reads, stays a plain store)
+template <int EPI, bool NTU = false>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                          int M, int N, int K, Work wk, EpiArgs e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -400,8 +403,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
         const bf16x8 vy = stg32_get(img_y, lane >> 2, lane & 3);
         if (p + 1 < 8 && p + 1 < 2 * t.u) put_g(p + 1);
         const int r0 = row0 + 16 * p + rr, ry = row0 + 16 * p + (lane >> 2);
-        if (r0 < M) NT256_STORE(bf16x8, e.C + (long)r0 * N + col, v0);
-        if (r0 + 8 < M) NT256_STORE(bf16x8, e.C + (long)(r0 + 8) * N + col, v1);
+        if (NTU) {
+          if (r0 < M) __builtin_nontemporal_store(v0, (bf16x8*)(e.C + (long)r0 * N + col));
+          if (r0 + 8 < M) __builtin_nontemporal_store(v1, (bf16x8*)(e.C + (long)(r0 + 8) * N + col));
+        } else {
+          if (r0 < M) NT256_STORE(bf16x8, e.C + (long)r0 * N + col, v0);
+          if (r0 + 8 < M) NT256_STORE(bf16x8, e.C + (long)(r0 + 8) * N + col, v1);
+        }
         if (ry < M) NT256_STORE(bf16x8, e.Y + (long)ry * (N >> 1) + ycol, vy);
       }
       return;
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
   WAIT_VM(0);                                               // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-template <int EPI>
+template <int EPI, bool NTU = false>
 static int launch(const void* A, const void* B, int M, int N, int K, const EpiArgs& e, hipStream_t st) {
   const int tm = cdiv(M, BM), tn = cdiv(N, BN);
   // column-group width of the tile order: an XCD's share of B (cg tiles of 256 x K bf16) should stay in its 4 MiB L2
@@ -648,7 +656,7 @@ static int launch(const void* A, const void* B, int M, int N, int K, const EpiAr
   static bool attr[64] = {};
   int devid = 0;
   if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return SNX_E_ARG;
-  auto kern = gemm_nt256_kernel<EPI>;
+  auto kern = gemm_nt256_kernel<EPI, NTU>;
   static bool done[64] = {};
   if (!done[devid]) {
     hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
@@ -697,7 +705,9 @@ int snx_launch_nt256(int epi, const void* A, const void* B, int M, int N, int K,
     case EPI_STORE_BF16: return launch<EPI_STORE_BF16>(A, B, M, N, K, e, st);
     case EPI_RESID_F32: return launch<EPI_RESID_F32>(A, B, M, N, K, e, st);
     case EPI_ROPE: return launch<EPI_ROPE>(A, B, M, N, K, e, st);
-    case EPI_GEGLU_FWD: return launch<EPI_GEGLU_FWD>(A, B, M, N, K, e, st);
+    case EPI_GEGLU_FWD:
+      return (g_snx_cfg.stream_nt & 8) ? launch<EPI_GEGLU_FWD, true>(A, B, M, N, K, e, st)
+                                       : launch<EPI_GEGLU_FWD>(A, B, M, N, K, e, st);
     case EPI_GEGLU_BWD: return launch<EPI_GEGLU_BWD>(A, B, M, N, K, e, st);
     default: return SNX_E_SHAPE;
   }

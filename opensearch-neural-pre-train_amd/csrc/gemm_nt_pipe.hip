@@ -87,7 +87,7 @@ enum { PERIOD_FIRST = 0, PERIOD_MIDDLE = 1, PERIOD_DRAIN = 2 };
 // NTS ("nt_pipe" = 1): du leaves through non-temporal stores -- 120 against 145 us per launch back to back (170 MB of
 // results that otherwise push the operands out of the L2 the K loops live on), but no faster inside the training step,
 // where the next two GEMMs read du (44.51 against 44.46 ms per micro-step): the default is plain stores.
-template <bool NTS>
+template <bool NTS, bool NTL = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_geglu_bwd_pipe_kernel(const bf16_t* __restrict__ A,
                                                                             const bf16_t* __restrict__ B, int M, int N,
                                                                             TileOrder order, int ntiles,
@@ -248,13 +248,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_geglu_bwd_pipe_kernel(con
     return;
 #endif
     const bf16_t* uu = U + base + unit_off(q);
-#if defined(SNX_PIPE_NT) && (SNX_PIPE_NT & 1)               // experiment: streaming (non-temporal) loads of the saved u
-    ua[q] = __builtin_nontemporal_load((const f32x4*)uu);
-    ug[q] = __builtin_nontemporal_load((const f32x4*)(uu + 32));
-#else
-    ua[q] = *(const f32x4*)uu;
-    ug[q] = *(const f32x4*)(uu + 32);
-#endif
+    if (NTL) {                                              // "stream_nt" bit 64: the saved u is read for the last time
+      ua[q] = __builtin_nontemporal_load((const f32x4*)uu);
+      ug[q] = __builtin_nontemporal_load((const f32x4*)(uu + 32));
+    } else {
+      ua[q] = *(const f32x4*)uu;
+      ug[q] = *(const f32x4*)(uu + 32);
+    }
   };
   auto read_pass = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -368,10 +368,12 @@ int snx_launch_nt_pipe_geglu_bwd(const void* A, const void* B, int M, int N, int
     }
   }
   TileOrder order{tm, tn, cdiv(tm, 8), cg};
-  static LdsOptIn optin[2];
+  static LdsOptIn optin[4];
   const bool nts = g_snx_cfg.nt_pipe == 1;                  // "nt_pipe": 2 = plain du stores (default), 1 = non-temporal
-  auto kern = nts ? gemm_nt_geglu_bwd_pipe_kernel<true> : gemm_nt_geglu_bwd_pipe_kernel<false>;
-  if (const int rc = optin[nts ? 1 : 0].ensure((const void*)kern, LDS_TOTAL)) return rc;
+  const bool ntl = (g_snx_cfg.stream_nt & 64) != 0;         // non-temporal loads of the saved u (its last read)
+  auto kern = nts ? (ntl ? gemm_nt_geglu_bwd_pipe_kernel<true, true> : gemm_nt_geglu_bwd_pipe_kernel<true, false>)
+                  : (ntl ? gemm_nt_geglu_bwd_pipe_kernel<false, true> : gemm_nt_geglu_bwd_pipe_kernel<false, false>);
+  if (const int rc = optin[(nts ? 1 : 0) + (ntl ? 2 : 0)].ensure((const void*)kern, LDS_TOTAL)) return rc;
   int nwg = 2 * (256 - snx_get_reserved_cus());             // two workgroups per CU
   if (nwg > tm * tn) nwg = (tm * tn + 7) & ~7;
   if (nwg < 8) nwg = 8;
