@@ -32,7 +32,8 @@ struct SnxConfig {
   int nt_pipe_min_m = 4096;
   int stream_nt = 0;          // non-temporal accesses of streams whose bytes have no reader soon (bitmask): 1 LayerNorm forward's
                               // loads of h and y, 2 its store of h_out, 4 LayerNorm backward's loads of the saved h and of dy,
-                              // 8 the GeGLU-forward GEMM's stores of the saved u, 32 the attention backward's loads of q, k, v,
+                              // 8 the GeGLU-forward GEMM's stores of the saved u, 16 the weight-gradient GEMM's operand LDS-DMA,
+                              // 32 the attention backward's loads of q, k, v,
                               // dO, 64 the GeGLU-backward GEMM's loads of the saved u
   int det_reduce = 1;         // weight gradients reduced in a FIXED order (partial slabs in the caller's workspace + an
                               // ordered reduction; bit-reproducible).  0: float atomics in arrival order (rounds 1-4; A/B)
