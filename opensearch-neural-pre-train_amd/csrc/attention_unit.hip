@@ -67,7 +67,7 @@ __device__ __forceinline__ Slot slot_of_block(const UnitSched& sc, const int32_t
 
 // Load rows [0, ntu*64) x 64 d of one tensor (row stride rs elements) into the unit's v_off image; rows past
 // the sequence repeat its last row (their products are masked).  2*RG 16-B pieces per thread.
-template <int RG>
+template <int RG, bool NT = false>
 __device__ __forceinline__ void load_image(const bf16_t* __restrict__ base, long rs, const Slot& t, char* img) {
   const int nthr = t.wpu * 64;
   bf16x8 v[2 * RG];
@@ -76,7 +76,8 @@ __device__ __forceinline__ void load_image(const bf16_t* __restrict__ base, long
     const int id = t.lt + i * nthr;
     const int r = id >> 3, c = id & 7;
     const int gr = r < t.slen ? r : t.slen - 1;
-    v[i] = *(const bf16x8*)(base + (long)gr * rs + c * 8);
+    v[i] = NT ? __builtin_nontemporal_load((const bf16x8*)(base + (long)gr * rs + c * 8))
+              : *(const bf16x8*)(base + (long)gr * rs + c * 8);
   }
 #pragma unroll
   for (int i = 0; i < 2 * RG; ++i) {
@@ -109,6 +110,8 @@ __device__ __forceinline__ void tile_range(int window, int row_lo, int slen, int
 }
 
 // ------------------------------------------------------------------------------------------ forward
+// NTL ("stream_nt" bit 32 ... see config.h: here the forward's reads of q, k, v, whose next reader is the backward)
+template <bool NTL>
 __global__ __launch_bounds__(NTMAX * 128, 4) void attn_fwd_unit_kernel(const bf16_t* __restrict__ qkv,
                                                                        const int32_t* __restrict__ cu_seqlens,
                                                                        const int64_t* __restrict__ mask,
@@ -133,7 +136,9 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_fwd_unit_kernel(const bf1
     const int qp = rg * 16 + li;
     const int qrow = qp < slen ? qp : (slen > 0 ? slen - 1 : 0);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) q[c] = *(const bf16x8*)(qbase + (long)qrow * rs + c * 32 + g * 8);
+    for (int c = 0; c < 2; ++c)
+      q[c] = NTL ? __builtin_nontemporal_load((const bf16x8*)(qbase + (long)qrow * rs + c * 32 + g * 8))
+                 : *(const bf16x8*)(qbase + (long)qrow * rs + c * 32 + g * 8);
   };
   // ONE round trip to memory before the barrier: the key mask and the first row group's Q fragments are requested ahead of
   // the K / V rows (as three trips -- images, then the mask, then Q after the barrier -- each cost every workgroup a
@@ -145,8 +150,8 @@ __global__ __launch_bounds__(NTMAX * 128, 4) void attn_fwd_unit_kernel(const bf1
     int64_t mv;
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(mv) : "v"(mask + s0 + key) : "memory");
     load_q(t.lw, qf);
-    load_image<2>(qbase + H, rs, t, sK);
-    load_image<2>(qbase + 2 * H, rs, t, sV);
+    load_image<2, NTL>(qbase + H, rs, t, sK);
+    load_image<2, NTL>(qbase + 2 * H, rs, t, sV);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(mv));           // the oldest request: long there after the image writes
     if (t.lt < ntu * 64) {                     // whole waves: ntu * 64 and the unit's first thread are multiples of 64
       const bool v = t.lt < slen && mv != 0;
@@ -532,9 +537,11 @@ int attn_unit_fwd(const bf16_t* qkv, const int32_t* cu_seqlens, const int64_t* m
   int blocks;
   const int rc = build_unit_sched(sc, blocks, groups, heads);
   if (rc != SNX_OK) return rc;
-  static LdsOptIn optin;
-  if (const int rc2 = optin.ensure((const void*)attn_fwd_unit_kernel, (int)UNIT_LDS)) return rc2;
-  hipLaunchKernelGGL(attn_fwd_unit_kernel, dim3(blocks), dim3(NTMAX * 128), UNIT_LDS, st, qkv, cu_seqlens, mask, out,
+  static LdsOptIn optin[2];
+  const bool ntl = (g_snx_cfg.stream_nt & 64) != 0;
+  auto kern = ntl ? attn_fwd_unit_kernel<true> : attn_fwd_unit_kernel<false>;
+  if (const int rc2 = optin[ntl ? 1 : 0].ensure((const void*)kern, (int)UNIT_LDS)) return rc2;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(NTMAX * 128), UNIT_LDS, st, qkv, cu_seqlens, mask, out,
                      lse, T, heads, window, 0.125f, sc);
   SNX_CHECK_LAUNCH();
   return SNX_OK;

@@ -10,6 +10,8 @@ struct SnxConfig {
   int nt256_min_m = 8192;     //   ... from this many rows on
   int nt256_coldeal = 1;      //   ... leftover 64-row units dealt along column runs: one short tile per workgroup (0: in tile
                               //   order, two short tiles for three workgroups in eight; A/B).  Same bits either way.
+  int nt256_rev = 0;          //   ... 1: the dX GEMMs with K >= 3 N walk every super-block's row panels from the last to the first
+                              //   (their A operand's last-written rows are the ones still in the Infinity Cache)
   int tn256 = 1;              // 256x256 persistent weight-gradient GEMM (0: the 128x128 kernel everywhere)
   int tn256_min_m = 8192;
   int dec256 = 1;             // 256x192 persistent decoder + SPLADE kernel (0: the 128x128 kernel)
@@ -30,11 +32,13 @@ struct SnxConfig {
                               // the next two GEMMs read du), 1 = non-temporal du stores (faster alone, equal in the step),
                               // 0 = gemm.hip's 128x128 kernel
   int nt_pipe_min_m = 4096;
-  int stream_nt = 0;          // non-temporal accesses of streams whose bytes have no reader soon (bitmask): 1 LayerNorm forward's
+  int stream_nt = 15;         // non-temporal accesses of streams whose bytes have no reader soon (bitmask): 1 LayerNorm forward's
                               // loads of h and y, 2 its store of h_out, 4 LayerNorm backward's loads of the saved h and of dy,
                               // 8 the GeGLU-forward GEMM's stores of the saved u, 16 the weight-gradient GEMM's operand LDS-DMA,
                               // 32 the attention backward's loads of q, k, v,
-                              // dO, 64 the GeGLU-backward GEMM's loads of the saved u
+                              // dO, 64 the GeGLU-backward GEMM's loads of the saved u and the attention forward's loads of q, k, v.  Default 15: measured
+                              // 43.72 against 44.22 ms per micro-step (three ABA rounds on one box; the NT GEMM classes gain
+                              // 0.45 ms: their operands stay cached); 16 costs 0.3 ms, 32 and 64 measured level
   int det_reduce = 1;         // weight gradients reduced in a FIXED order (partial slabs in the caller's workspace + an
                               // ordered reduction; bit-reproducible).  0: float atomics in arrival order (rounds 1-4; A/B)
 #ifdef SNX_DIAG

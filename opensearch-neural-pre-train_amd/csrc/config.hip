@@ -13,6 +13,7 @@ const Key KEYS[] = {
     {"nt256", &SnxConfig::nt256, 0, 2},
     {"nt256_min_m", &SnxConfig::nt256_min_m, 1, 1 << 30},
     {"nt256_coldeal", &SnxConfig::nt256_coldeal, 0, 1},
+    {"nt256_rev", &SnxConfig::nt256_rev, 0, 1},
     {"tn256", &SnxConfig::tn256, 0, 1},
     {"tn256_min_m", &SnxConfig::tn256_min_m, 1, 1 << 30},
     {"dec256", &SnxConfig::dec256, 0, 1},

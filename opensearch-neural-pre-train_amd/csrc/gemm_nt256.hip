@@ -79,6 +79,7 @@ struct Work {
                                      // 4 = write-back without its global stores, 8 = stores drain at once (no vmcnt slack),
                                      // 16 = no deep request at tile boundaries
   int coldeal;                       // leftover units dealt along COLUMN runs (round 6, see next_tile)
+  int rev;                           // row panels of every super-block walked from the last to the first ("nt256_rev")
 };
 
 struct Tile { int m0, n0, u; };      // first row, first column, 64-row units (0: no tile)
@@ -152,6 +153,16 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
   int y = (int)(4L * nleft * jw / per);
   const int ye = (int)(4L * nleft * (jw + 1) / per);
 
+  // "nt256_rev": the A operand of a dX GEMM (du, dqkv: 170 MB) was written row panel by row panel, in ascending order, by a
+  // kernel that streamed more bytes than the 256 MiB Infinity Cache holds: what is still cached when this kernel starts are
+  // the LAST rows written.  Walked in the same ascending order, the first (evicted) rows' misses push the cached tail out
+  // before it is reached -- the classic LRU wipe-out; walked from the last panel to the first, the tail is read while it is
+  // still there.  Which workgroup computes which tile changes no tile's arithmetic.
+  auto rev_panel = [&](int pm) __attribute__((always_inline)) {
+    const int sb = pm / wk.order.sb_rows;
+    const int rows = wk.order.tm - sb * wk.order.sb_rows < wk.order.sb_rows ? wk.order.tm - sb * wk.order.sb_rows : wk.order.sb_rows;
+    return sb * wk.order.sb_rows + (rows - 1 - (pm - sb * wk.order.sb_rows));
+  };
   auto next_tile = [&]() __attribute__((always_inline)) {                                  // u = 0: none
     Tile t;
     t.m0 = 0; t.n0 = 0; t.u = 0;
@@ -159,6 +170,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
     if (kround < nround) {
       tile_of(wk.order, (int)(P0 + (long)kround * per + jw), pm, pn);
       ++kround;
+      if (wk.rev) pm = rev_panel(pm);
       t.m0 = pm * BM; t.n0 = pn * BN; t.u = 4;
       return t;
     }
@@ -177,7 +189,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
           const int o = y - cum;
           int uu = ye - y < 4 ? ye - y : 4;
           uu = 4 * cnt - o < uu ? 4 * cnt - o : uu;
-          t.m0 = (sb * wk.order.sb_rows + first) * BM + 64 * o;
+          int top = sb * wk.order.sb_rows + first;
+          if (wk.rev) top = rev_panel(sb * wk.order.sb_rows + last);          // the run's rows, mirrored inside the super-block
+          t.m0 = top * BM + 64 * o;
           t.n0 = c * BN;
           t.u = uu;
           y += uu;
@@ -192,6 +206,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
     const long left = xe - x;
     t.u = 4 - q0 < left ? 4 - q0 : (int)left;
     tile_of(wk.order, (int)(x >> 2), pm, pn);
+    if (wk.rev) pm = rev_panel(pm);
     t.m0 = pm * BM + q0 * 64;
     t.n0 = pn * BN;
     x += t.u;
@@ -641,6 +656,9 @@ static int launch(const void* A, const void* B, int M, int N, int K, const EpiAr
   wk.dbg = dbg;
   // column-run dealing of the leftover units: needs position -> (p / tn, p % tn) inside a super-block, i.e. ONE column
   // group, and every XCD's leftover tiles inside one super-block ("nt256_coldeal" = 0: the round-3 dealing, for A/B)
+  // reverse walk for the launches whose A operand is the big, just-written gradient tensor: the plain-store dX GEMMs with a
+  // long contraction (K >= 3 N: du / dqkv against Wi^T / Wqkv^T)
+  wk.rev = (g_snx_cfg.nt256_rev != 0 && EPI == EPI_STORE_BF16 && K >= 3 * N) ? 1 : 0;
   wk.coldeal = 0;
   {
     const int nwg_ = NWG - snx_get_reserved_cus(), per = nwg_ >> 3;

@@ -647,8 +647,8 @@ def test_gemm_nt256_all_epilogues_equal_the_128_kernel_bit_for_bit(dev, M, N, K)
         fn("snx_nt256_configure")(1, 8192)
 
 
-@pytest.mark.parametrize("M,N,K", [(36864, 768, 2304), (36864, 768, 768), (36864, 2304, 768), (20037, 768, 1152),
-                                   (9000, 512, 384), (33333, 1280, 320)])
+@pytest.mark.parametrize("M,N,K", [(36864, 768, 2304), (36864, 768, 768), (36864, 2304, 768), (20037, 768, 2304),
+                                   (9000, 256, 768), (33333, 1280, 320)])
 def test_gemm_nt256_column_run_dealing_of_the_leftover_units(dev, M, N, K):
     """Round 6: the 64-row units left after the whole rounds of tiles are dealt along the leftover tiles' COLUMN runs (one
     short tile per workgroup, its rows free to cross a row-panel boundary) instead of in tile order (two short tiles for
@@ -669,15 +669,19 @@ def test_gemm_nt256_column_run_dealing_of_the_leftover_units(dev, M, N, K):
     try:
         fn("snx_nt256_configure")(2, 1024)
         for name, f in calls.items():
-            assert fn("snx_configure")(b"nt256_coldeal", 0) == 0
+            assert fn("snx_configure")(b"nt256_coldeal", 0) == 0 and fn("snx_configure")(b"nt256_rev", 0) == 0
             ref = [t.clone() for t in f()]
-            assert fn("snx_configure")(b"nt256_coldeal", 1) == 0
-            got = f()
-            torch.cuda.synchronize()
-            for a, b in zip(ref, got):
-                assert torch.equal(a, b), (name, M, N, K, float((a.float() - b.float()).abs().max()))
+            # ... and "nt256_rev" (the K >= 3 N plain stores walk their row panels from the last to the first): another
+            # tile -> workgroup assignment again, the same tiles
+            for coldeal, rev in ((1, 0), (1, 1), (0, 1)):
+                assert fn("snx_configure")(b"nt256_coldeal", coldeal) == 0 and fn("snx_configure")(b"nt256_rev", rev) == 0
+                got = f()
+                torch.cuda.synchronize()
+                for a, b in zip(ref, got):
+                    assert torch.equal(a, b), (name, M, N, K, coldeal, rev, float((a.float() - b.float()).abs().max()))
     finally:
         fn("snx_configure")(b"nt256_coldeal", 1)
+        fn("snx_configure")(b"nt256_rev", 0)
         fn("snx_nt256_configure")(1, 8192)
 
 
