@@ -386,13 +386,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       for (int e = 0; e < 4; ++e) g.v[i][e] = rstd * (g.v[i][e] - s1 - x.v[i][e] * s2);   // g = dx
     if (MODE == 0) {
       RowVec<NV> cur;
-      cur.load_f32(dh + (long)t * H, lane);
+      if (nt & 128) cur.load_f32_nt(dh + (long)t * H, lane);   // (experiment: the fp32 gradient stream, next touched by the
+      else cur.load_f32(dh + (long)t * H, lane);               // next LayerNorm backward three kernels later)
 #pragma unroll
       for (int i = 0; i < NV; ++i) cur.v[i] += g.v[i];
-      cur.store_f32(dh + (long)t * H, lane);
+      if (nt & 128) cur.store_f32_nt(dh + (long)t * H, lane);
+      else cur.store_f32(dh + (long)t * H, lane);
       if (dh_bf16) cur.store_bf16(dh_bf16 + (long)t * H, lane);   // grad of the next bf16 branch output
     } else if (MODE == 3) {
-      g.store_f32(dh + (long)t * H, lane);
+      if (nt & 128) g.store_f32_nt(dh + (long)t * H, lane);
+      else g.store_f32(dh + (long)t * H, lane);
+
       if (dh_bf16) g.store_bf16(dh_bf16 + (long)t * H, lane);
     } else if (MODE == 1 && dw_part) {
       g.store_f32(dh + (long)t * H, lane);               // dx row; summed per vocabulary id, in token order, by embed_scatter_kernel
@@ -766,11 +770,13 @@ int snx_ln_bwd_x(const void* dy, const float* h, const float* w, float* dh, void
   DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<NV, MODE_, NT_>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, \
                                     nullptr, h, nullptr, nullptr, nullptr, w, dh, (bf16_t*)dh_bf16, nullptr, nullptr, \
                                     dw, part, T, H, eps, rpb, -1))
-  const bool nt = (g_snx_cfg.stream_nt & 4) != 0;
+  const int nt = g_snx_cfg.stream_nt & (4 | 128);
   if (overwrite) {
-    if (nt) { SNX_LN_BWD_LAUNCH(3, 4); } else { SNX_LN_BWD_LAUNCH(3, 0); }
+    if (nt == 132) { SNX_LN_BWD_LAUNCH(3, 132); } else if (nt == 128) { SNX_LN_BWD_LAUNCH(3, 128); }
+    else if (nt == 4) { SNX_LN_BWD_LAUNCH(3, 4); } else { SNX_LN_BWD_LAUNCH(3, 0); }
   } else {
-    if (nt) { SNX_LN_BWD_LAUNCH(0, 4); } else { SNX_LN_BWD_LAUNCH(0, 0); }
+    if (nt == 132) { SNX_LN_BWD_LAUNCH(0, 132); } else if (nt == 128) { SNX_LN_BWD_LAUNCH(0, 128); }
+    else if (nt == 4) { SNX_LN_BWD_LAUNCH(0, 4); } else { SNX_LN_BWD_LAUNCH(0, 0); }
   }
 #undef SNX_LN_BWD_LAUNCH
   SNX_CHECK_LAUNCH();

@@ -257,7 +257,9 @@ __device__ __forceinline__ float splade_coef(float g, uint32_t key) {
 // (with one wave per vocab row running its own sweep the gathers touched all of Hd at once and
 // every 1.5 KB row crossed the fabric: 13.6 GB per 192-sequence step, 7.6 TB/s, 1.8 ms).
 // Zero coefficients (most entries once the model is trained) are skipped wave-uniformly.
-template <int NV>
+// NT ("splade_dw_last"): the read-modify-write of the gradient rows (2 x 153 MB, no reader before the optimizer / the
+// embedding unit at the end of the backward) through non-temporal accesses
+template <int NV, bool NT = false>
 __global__ __launch_bounds__(256) void splade_bwd_dw_kernel(const float* __restrict__ g,
                                                             const uint32_t* __restrict__ keys,
                                                             const bf16_t* __restrict__ Hd,
@@ -327,7 +329,8 @@ __global__ __launch_bounds__(256) void splade_bwd_dw_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       f32x4* p = (f32x4*)(dst + (i * 64 + lane) * 4);
-      *p = *p + acc[k][i];
+      if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(p) + acc[k][i], p);
+      else *p = *p + acc[k][i];
     }
   }
 }
@@ -685,13 +688,32 @@ extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* 
   if (!g || !keys || !Hd || !W || !cu_seqlens || !dHd || !gradE || !gradb || !scratch) return SNX_E_ARG;
   if (T <= 0 || nseq <= 0 || V <= 0 || max_seqlen <= 0 || H <= 0 || (H % 256) || H > 1024) return SNX_E_SHAPE;
   const int blocks = cdiv(V, 32);               // 4 waves x 8 vocab rows per workgroup
-  switch (H / 256) {
-    case 1: hipLaunchKernelGGL(splade_bwd_dw_kernel<1>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
-    case 2: hipLaunchKernelGGL(splade_bwd_dw_kernel<2>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
-    case 3: hipLaunchKernelGGL(splade_bwd_dw_kernel<3>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
-    default: hipLaunchKernelGGL(splade_bwd_dw_kernel<4>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+  // "splade_dw_last" = 1 (round 6): the weight half (dE, db) AFTER the activation half.  The dHd gather below is bound by
+  // how fast W_E rows (77 MB) come out of the Infinity Cache, where the decoder forward has just left them; run first, the
+  // weight half's read-modify-write of the 153 MB gradient matrix pushes them out.  (Then also with non-temporal accesses
+  // to the gradient rows: nobody reads them before the end of the backward.)
+  const bool dw_last = g_snx_cfg.splade_dw_last != 0;
+  auto launch_dw = [&]() {
+    if (dw_last) {
+      switch (H / 256) {
+        case 1: hipLaunchKernelGGL((splade_bwd_dw_kernel<1, true>), dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+        case 2: hipLaunchKernelGGL((splade_bwd_dw_kernel<2, true>), dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+        case 3: hipLaunchKernelGGL((splade_bwd_dw_kernel<3, true>), dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+        default: hipLaunchKernelGGL((splade_bwd_dw_kernel<4, true>), dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+      }
+    } else {
+      switch (H / 256) {
+        case 1: hipLaunchKernelGGL(splade_bwd_dw_kernel<1>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+        case 2: hipLaunchKernelGGL(splade_bwd_dw_kernel<2>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+        case 3: hipLaunchKernelGGL(splade_bwd_dw_kernel<3>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+        default: hipLaunchKernelGGL(splade_bwd_dw_kernel<4>, dim3(blocks), dim3(256), 0, st, g, keys, (const bf16_t*)Hd, cu_seqlens, gradE, gradb, nseq, V, H); break;
+      }
+    }
+  };
+  if (!dw_last) {
+    launch_dw();
+    SNX_CHECK_LAUNCH();
   }
-  SNX_CHECK_LAUNCH();
   // dHd: bucket by row, then one wave per token row
   if (max_seqlen > 8192) return SNX_E_SHAPE;
   char* sc = (char*)scratch;
@@ -729,6 +751,10 @@ extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* 
     }
 #undef SNX_DH_PANELS
     SNX_CHECK_LAUNCH();
+    if (dw_last) {
+      launch_dw();
+      SNX_CHECK_LAUNCH();
+    }
     return SNX_OK;
   }
   const dim3 grid(cdiv(max_seqlen, 4), nseq);
@@ -739,5 +765,9 @@ extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* 
     default: hipLaunchKernelGGL(splade_bwd_dh_rows_kernel<4>, grid, dim3(256), 0, st, list_v, list_c, row_off, (const bf16_t*)W, cu_seqlens, (bf16_t*)dHd, V, H, max_seqlen); break;
   }
   SNX_CHECK_LAUNCH();
+  if (dw_last) {
+    launch_dw();
+    SNX_CHECK_LAUNCH();
+  }
   return SNX_OK;
 }
