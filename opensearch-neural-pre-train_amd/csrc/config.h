@@ -23,7 +23,8 @@ struct SnxConfig {
   int attn_interleave = 0;    // 1: units of the sequence groups interleaved in proportion (attention_common.h); default 0 =
                               // group by group, longest first -- measured level in the step (45.08 against 45.01 ms, ABAB)
   int splade_dh_panels = 16;  // vocabulary panels of the routed decoder backward's dHd gather (0: one wave per row)
-  int splade_dw_last = 0;     // 1: routed decoder backward's weight half after its activation half, gradient rows non-temporal
+  int splade_dw_last = 1;     // routed decoder backward's weight half AFTER its activation half, gradient rows non-temporal: the dHd
+                              // gather finds W_E where the decoder forward left it (44.17 against 44.27 ms, ABAB; 0: before)
   int f32_gemm64 = 0;         // fp32 path: the 64x64 GEMM tile for every shape
   int f32_attn_rows = 0;      // fp32 path: wave-per-(token, head) attention forward
   int wcache_per_tensor = 0;  // bf16 weight cache refreshed one launch per tensor
