@@ -24,7 +24,7 @@ const Key KEYS[] = {
     {"attn_bwd_onepass", &SnxConfig::attn_bwd_onepass, 0, 1},
     {"attn_interleave", &SnxConfig::attn_interleave, 0, 1},
     {"splade_dh_panels", &SnxConfig::splade_dh_panels, 0, 64},
-    {"splade_dw_last", &SnxConfig::splade_dw_last, 0, 1},
+    {"splade_dw_last", &SnxConfig::splade_dw_last, 0, 2},
     {"f32_gemm64", &SnxConfig::f32_gemm64, 0, 1},
     {"f32_attn_rows", &SnxConfig::f32_attn_rows, 0, 1},
     {"wcache_per_tensor", &SnxConfig::wcache_per_tensor, 0, 1},

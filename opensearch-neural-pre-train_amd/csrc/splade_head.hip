@@ -570,7 +570,9 @@ __global__ __launch_bounds__(256) void splade_dh_items_kernel(const int32_t* __r
   }
 }
 
-template <int NV>
+// NTL ("splade_dw_last" = 2): the bucket lists (77 MB, read once) through non-temporal loads -- the gather is bound by how
+// fast W_E rows come out of the Infinity Cache, and everything else that passes through it competes with them
+template <int NV, bool NTL = false>
 __global__ __launch_bounds__(256) void splade_bwd_dh_panels_kernel(const int32_t* __restrict__ list_v,
                                                                    const float* __restrict__ list_c,
                                                                    const int32_t* __restrict__ row_off,
@@ -618,8 +620,8 @@ __global__ __launch_bounds__(256) void splade_bwd_dh_panels_kernel(const int32_t
       end[j] = live ? ro[row + 1] : 0;
       cbase[j] = cur[j];
       const int e = cbase[j] + lane;
-      cv[j] = e < end[j] ? lv[e] : 0x7FFFFFFF;
-      cc[j] = e < end[j] ? lc[e] : 0.f;
+      cv[j] = e < end[j] ? (NTL ? __builtin_nontemporal_load(lv + e) : lv[e]) : 0x7FFFFFFF;
+      cc[j] = e < end[j] ? (NTL ? __builtin_nontemporal_load(lc + e) : lc[e]) : 0.f;
     }
 #pragma unroll 1
     for (int p = 0; p < npanel; ++p) {
@@ -659,8 +661,8 @@ __global__ __launch_bounds__(256) void splade_bwd_dh_panels_kernel(const int32_t
           if (first + n < 64) break;                  // the chunk's next entry belongs to a later panel (or the bucket ended)
           cbase[j] = cur[j];                          // chunk used up: the next 64 entries
           const int e = cbase[j] + lane;
-          cv[j] = e < end[j] ? lv[e] : 0x7FFFFFFF;
-          cc[j] = e < end[j] ? lc[e] : 0.f;
+          cv[j] = e < end[j] ? (NTL ? __builtin_nontemporal_load(lv + e) : lv[e]) : 0x7FFFFFFF;
+          cc[j] = e < end[j] ? (NTL ? __builtin_nontemporal_load(lc + e) : lc[e]) : 0.f;
         }
       }
     }
@@ -740,9 +742,16 @@ extern "C" int snx_splade_bwd(const float* g, const uint32_t* keys, const void* 
     hipLaunchKernelGGL(splade_dh_items_kernel, dim3(1), dim3(256), 0, st, cu_seqlens, items, nseq, max_seqlen);
     SNX_CHECK_LAUNCH();
     const dim3 pgrid(DH_WGS);
+    const bool ntl = g_snx_cfg.splade_dw_last >= 2;
 #define SNX_DH_PANELS(NVV)                                                                                                  \
-  hipLaunchKernelGGL(splade_bwd_dh_panels_kernel<NVV>, pgrid, dim3(256), 0, st, list_v, list_c, row_off, items, (const bf16_t*)W, \
-                     cu_seqlens, (bf16_t*)dHd, V, H, max_seqlen, nseq, panels, items + nseq + 1)
+  do {                                                                                                                      \
+    if (ntl)                                                                                                                \
+      hipLaunchKernelGGL((splade_bwd_dh_panels_kernel<NVV, true>), pgrid, dim3(256), 0, st, list_v, list_c, row_off, items,  \
+                         (const bf16_t*)W, cu_seqlens, (bf16_t*)dHd, V, H, max_seqlen, nseq, panels, items + nseq + 1);      \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((splade_bwd_dh_panels_kernel<NVV, false>), pgrid, dim3(256), 0, st, list_v, list_c, row_off, items, \
+                         (const bf16_t*)W, cu_seqlens, (bf16_t*)dHd, V, H, max_seqlen, nseq, panels, items + nseq + 1);      \
+  } while (0)
     switch (H / 256) {
       case 1: SNX_DH_PANELS(1); break;
       case 2: SNX_DH_PANELS(2); break;
