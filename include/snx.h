@@ -267,7 +267,7 @@ int snx_gemm_tn_accum_group(const snx_tn_problem* probs /*[host]*/, int32_t npro
  * same bits), tn256 (1), tn256_min_m (8192),
  * dec256 (1), dec256_min_t (2048), bwd_overlap (1), side_prio (1), attn_streaming (0), attn_bwd_onepass (1),
  * attn_interleave (0; 1: the workgroups of a launch's sequence groups interleaved in proportion instead of group by group),
- * splade_dh_panels (16), f32_gemm64 (0), f32_attn_rows (0), wcache_per_tensor (0), resid_in_ln (1: the Wo GEMMs store
+ * splade_dh_panels (32), splade_dw_last (2: the routed decoder backward runs its activation half first, gradient rows and bucket lists non-temporal), f32_gemm64 (0), f32_attn_rows (0), wcache_per_tensor (0), resid_in_ln (1: the Wo GEMMs store
  * bf16 and the residual add happens inside the following LayerNorm; 0: in the GEMMs' fp32 epilogue, same bits),
  * det_reduce (1: weight gradients -- Linear dW, LayerNorm dw, embedding rows -- summed in a fixed order through the callers'
  * workspaces, bit-reproducible; 0: float atomics in arrival order); diagnostics builds (-DSNX_DIAG) add

@@ -22,9 +22,11 @@ struct SnxConfig {
   int attn_bwd_onepass = 1;   // one-pass attention backward for sequences of <= 256 tokens (0: dQ + dK/dV pair)
   int attn_interleave = 0;    // 1: units of the sequence groups interleaved in proportion (attention_common.h); default 0 =
                               // group by group, longest first -- measured level in the step (45.08 against 45.01 ms, ABAB)
-  int splade_dh_panels = 16;  // vocabulary panels of the routed decoder backward's dHd gather (0: one wave per row)
-  int splade_dw_last = 1;     // routed decoder backward's weight half AFTER its activation half, gradient rows non-temporal: the dHd
-                              // gather finds W_E where the decoder forward left it (44.17 against 44.27 ms, ABAB; 0: before)
+  int splade_dh_panels = 32;  // vocabulary panels of the routed decoder backward's dHd gather (0: one wave per row); rounds 3-5: 16,
+                              // round 6 with the activation half first and nt bucket lists: 32 (3.12 against 3.21 ms for the class)
+  int splade_dw_last = 2;     // routed decoder backward's weight half AFTER its activation half, gradient rows non-temporal: the dHd
+                              // gather finds W_E where the decoder forward left it (44.17 against 44.27 ms, ABAB; 0: before);
+                              // 2: also the bucket lists (read once) through non-temporal loads
   int f32_gemm64 = 0;         // fp32 path: the 64x64 GEMM tile for every shape
   int f32_attn_rows = 0;      // fp32 path: wave-per-(token, head) attention forward
   int wcache_per_tensor = 0;  // bf16 weight cache refreshed one launch per tensor
