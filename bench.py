@@ -117,9 +117,9 @@ def cpu_baseline(seconds_budget: float = 30.0, cores: int | None = None):
 PMC_KERNELS = {
     "gemm_nt_bf16": ["gemm_nt_kernel<128, 128, 2, 2, 0", "gemm_nt_kernel<128, 128, 2, 2, 2",
                      "gemm_nt_kernel<128, 128, 2, 2, 3", "gemm_nt_kernel<128, 128, 2, 2, 4",
-                     "gemm_nt256_kernel<0>", "gemm_nt256_kernel<2>", "gemm_nt256_kernel<3>", "gemm_nt256_kernel<4>",
+                     "gemm_nt256_kernel<0", "gemm_nt256_kernel<2", "gemm_nt256_kernel<3", "gemm_nt256_kernel<4",
                      "gemm_nt_geglu_bwd_pipe_kernel"],
-    "gemm_nt_resid": ["gemm_nt_kernel<128, 128, 2, 2, 1", "gemm_nt256_kernel<1>"],
+    "gemm_nt_resid": ["gemm_nt_kernel<128, 128, 2, 2, 1", "gemm_nt256_kernel<1"],
     "gemm_tn_accum": ["gemm_tn256_kernel", "gemm_tn_kernel"],
     "decoder_splade_fwd": ["decoder256_kernel", "decoder_splade_kernel"],
     "attn_fwd": ["attn_fwd_unit_kernel", "attn_fwd_kernel"],

@@ -30,7 +30,7 @@ const Key KEYS[] = {
     {"wcache_per_tensor", &SnxConfig::wcache_per_tensor, 0, 1},
     {"resid_in_ln", &SnxConfig::resid_in_ln, 0, 1},
     {"det_reduce", &SnxConfig::det_reduce, 0, 1},
-    {"stream_nt", &SnxConfig::stream_nt, 0, 255},
+    {"stream_nt", &SnxConfig::stream_nt, 0, 511},
     {"nt_pipe", &SnxConfig::nt_pipe, 0, 2},
     {"nt_pipe_min_m", &SnxConfig::nt_pipe_min_m, 1, 1 << 30},
 #ifdef SNX_DIAG

@@ -417,6 +417,9 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
 // chunk); a thread owns 4 consecutive k of 4 rows: every access is a whole 16-byte piece of a 1-KiB row.  The slabs were
 // written a moment ago by the GEMM kernel (the group's 60-100 MB sit in the 256-MiB Infinity Cache).  (32-row chunks:
 // 624 workgroups for the layer group = 2.4 per CU, three rounds of ~10 us; 16-row chunks: 1,248.)
+// NT ("stream_nt" bit 256): the slabs are read for the last time and the gradient tile is not read again before the
+// optimizer -- non-temporal accesses keep both out of the way of the launch stream's operands.
+template <bool NT>
 __global__ __launch_bounds__(256) void tn256_reduce_kernel(TnGroup grp, Sched sch) {
   const int tile = blockIdx.x, chunk = blockIdx.y;
   const Tile t = decode(grp, tile);
@@ -432,13 +435,17 @@ __global__ __launch_bounds__(256) void tn256_reduce_kernel(TnGroup grp, Sched sc
     if (n >= t.N) continue;
     if (t.inter > 0) n = ((n & 63) < 32) ? 32 * (n >> 6) + (n & 31) : t.inter + 32 * (n >> 6) + (n & 31);
     float* dst = t.dw + (long)n * t.K + k;
-    f32x4 a = *(const f32x4*)dst;
+    auto ld = [](const float* p_) __attribute__((always_inline)) {
+      return NT ? __builtin_nontemporal_load((const f32x4*)p_) : *(const f32x4*)p_;
+    };
+    f32x4 a = ld(dst);
     const float* src = sch.ws + (size_t)tile * (256 * 256) + nl * 256 + col;
     for (int p = 0; p < sch.P; ++p) {
-      if (p * sch.main_len / sch.P < (p + 1) * sch.main_len / sch.P) a += *(const f32x4*)(src + p * tile_stride);
+      if (p * sch.main_len / sch.P < (p + 1) * sch.main_len / sch.P) a += ld(src + p * tile_stride);
     }
-    for (int c = 0; c < ntail; ++c) a += *(const f32x4*)(src + (sch.P + c) * tile_stride);
-    *(f32x4*)dst = a;
+    for (int c = 0; c < ntail; ++c) a += ld(src + (sch.P + c) * tile_stride);
+    if (NT) __builtin_nontemporal_store(a, (f32x4*)dst);
+    else *(f32x4*)dst = a;
   }
 }
 
@@ -527,7 +534,8 @@ int snx_launch_tn256(const TnGroup& g128, int M, void* ws, size_t ws_bytes, hipS
   hipLaunchKernelGGL(kern, dim3(NWG), dim3(256), RING * SLOT, st, g, M, s);
   SNX_CHECK_LAUNCH();
   if (s.ws && !(dbg & 1)) {
-    hipLaunchKernelGGL(tn256_reduce_kernel, dim3(s.ntiles, 16), dim3(256), 0, st, g, s);
+    if (g_snx_cfg.stream_nt & 256) hipLaunchKernelGGL(tn256_reduce_kernel<true>, dim3(s.ntiles, 16), dim3(256), 0, st, g, s);
+    else hipLaunchKernelGGL(tn256_reduce_kernel<false>, dim3(s.ntiles, 16), dim3(256), 0, st, g, s);
     SNX_CHECK_LAUNCH();
   }
   return SNX_OK;
