@@ -267,11 +267,12 @@ int snx_gemm_tn_accum_group(const snx_tn_problem* probs /*[host]*/, int32_t npro
  * same bits), tn256 (1), tn256_min_m (8192),
  * dec256 (1), dec256_min_t (2048), bwd_overlap (1), side_prio (1), attn_streaming (0), attn_bwd_onepass (1),
  * attn_interleave (0; 1: the workgroups of a launch's sequence groups interleaved in proportion instead of group by group),
- * splade_dh_panels (32), splade_dw_last (2: the routed decoder backward runs its activation half first, gradient rows and bucket lists non-temporal), f32_gemm64 (0), f32_attn_rows (0), wcache_per_tensor (0), resid_in_ln (1: the Wo GEMMs store
+ * splade_dh_panels (64), splade_dw_last (2: the routed decoder backward runs its activation half first, gradient rows and bucket lists non-temporal), f32_gemm64 (0), f32_attn_rows (0), wcache_per_tensor (0), resid_in_ln (1: the Wo GEMMs store
  * bf16 and the residual add happens inside the following LayerNorm; 0: in the GEMMs' fp32 epilogue, same bits),
- * stream_nt (15; bitmask of non-temporal accesses for streams nobody reads soon: 1 LayerNorm forward's loads of h and y,
+ * stream_nt (271 = 15 + 256; bitmask of non-temporal accesses for streams nobody reads soon: 1 LayerNorm forward's loads of h and y,
  * 2 its store of h_out, 4 LayerNorm backward's loads of the saved h and of dy, 8 the GeGLU-forward GEMM's stores of the saved
- * u; 16 / 32 / 64 / 128: measured-level or losing variants kept for A/B -- a cache hint, same bits), nt256_rev (0),
+ * u, 256 the weight-gradient GEMM's ordered reduce; 16 / 32 / 64 / 128: measured-level or losing variants kept for A/B -- a
+ * cache hint, same bits), nt256_rev (0),
  * det_reduce (1: weight gradients -- Linear dW, LayerNorm dw, embedding rows -- summed in a fixed order through the callers'
  * workspaces, bit-reproducible; 0: float atomics in arrival order); diagnostics builds (-DSNX_DIAG) add
  * gemm_cg, gemm_dbg, gemm_mid, tn_splits, nt256_cg, nt256_dbg, nt256_force, tn256_tail_pct, tn256_dbg.  Unknown key or

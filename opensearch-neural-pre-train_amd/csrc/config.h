@@ -22,8 +22,8 @@ struct SnxConfig {
   int attn_bwd_onepass = 1;   // one-pass attention backward for sequences of <= 256 tokens (0: dQ + dK/dV pair)
   int attn_interleave = 0;    // 1: units of the sequence groups interleaved in proportion (attention_common.h); default 0 =
                               // group by group, longest first -- measured level in the step (45.08 against 45.01 ms, ABAB)
-  int splade_dh_panels = 32;  // vocabulary panels of the routed decoder backward's dHd gather (0: one wave per row); rounds 3-5: 16,
-                              // round 6 with the activation half first and nt bucket lists: 32 (3.12 against 3.21 ms for the class)
+  int splade_dh_panels = 64;  // vocabulary panels of the routed decoder backward's dHd gather (0: one wave per row); rounds 3-5: 16,
+                              // round 6 with the activation half first and nt bucket lists: 64 (3.07 / 3.12 / 3.21 ms at 64 / 32 / 16)
   int splade_dw_last = 2;     // routed decoder backward's weight half AFTER its activation half, gradient rows non-temporal: the dHd
                               // gather finds W_E where the decoder forward left it (44.17 against 44.27 ms, ABAB; 0: before);
                               // 2: also the bucket lists (read once) through non-temporal loads
@@ -36,11 +36,12 @@ struct SnxConfig {
                               // the next two GEMMs read du), 1 = non-temporal du stores (faster alone, equal in the step),
                               // 0 = gemm.hip's 128x128 kernel
   int nt_pipe_min_m = 4096;
-  int stream_nt = 15;         // non-temporal accesses of streams whose bytes have no reader soon (bitmask): 1 LayerNorm forward's
+  int stream_nt = 271;         // non-temporal accesses of streams whose bytes have no reader soon (bitmask): 1 LayerNorm forward's
                               // loads of h and y, 2 its store of h_out, 4 LayerNorm backward's loads of the saved h and of dy,
                               // 8 the GeGLU-forward GEMM's stores of the saved u, 16 the weight-gradient GEMM's operand LDS-DMA,
                               // 32 the attention backward's loads of q, k, v,
-                              // dO, 64 the GeGLU-backward GEMM's loads of the saved u and the attention forward's loads of q, k, v.  Default 15: measured
+                              // dO, 64 the GeGLU-backward GEMM's loads of the saved u and the attention forward's loads of q, k, v, 128 LayerNorm backward's load + store of the fp32 gradient stream dh, 256 the weight-gradient
+                              // GEMM's ordered reduce (slab loads, gradient-tile read-modify-write).  Default 271 = 15 + 256: 15 measured
                               // 43.72 against 44.22 ms per micro-step (three ABA rounds on one box; the NT GEMM classes gain
                               // 0.45 ms: their operands stay cached); 16 costs 0.3 ms, 32 and 64 measured level
   int det_reduce = 1;         // weight gradients reduced in a FIXED order (partial slabs in the caller's workspace + an
