@@ -375,6 +375,14 @@ extern "C" int snx_model_forward_range(const snx_model_desc* d, const void* cons
   CachePlan c;
   SavedPlan s;
   if (!plan_cache(d, c) || !plan_saved(d, T_plan, nseq_plan, save, s)) return SNX_E_SHAPE;
+  // The forward's non-temporal streams ("stream_nt" bits 1, 2, 8: residual-stream rows, the saved u) are a TRAINING policy:
+  // without a backward the stream ping-pongs between two buffers and small inference batches live in the caches -- an nt
+  // store would send the next LayerNorm to HBM for them.  (One thread drives the library: the switch is restored on return.)
+  struct NtScope {
+    int saved;
+    explicit NtScope(bool keep) : saved(g_snx_cfg.stream_nt) { if (!keep) g_snx_cfg.stream_nt &= ~(1 | 2 | 8); }
+    ~NtScope() { g_snx_cfg.stream_nt = saved; }
+  } nt_scope(save);
   PIdx p{d->layers};
   const char* wc = (const char*)wcache;
   const int H = d->hidden, I = d->inter, V = d->vocab, L = d->layers;
