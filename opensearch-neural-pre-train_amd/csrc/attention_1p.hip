@@ -50,10 +50,7 @@ constexpr int OFF_DS = OFF_O + 4 * PS_S;       // [256 keys][64 q] bf16, 128-B r
 constexpr int OFF_LSE = OFF_DS + MAXK * 128;   // -lse / scale per query
 constexpr int OFF_DEL = OFF_LSE + MAXK * 4;    // -delta per query
 constexpr int OFF_POS = OFF_DEL + MAXK * 4;    // RoPE position per token
-constexpr int OFF_PF = OFF_POS + MAXK * 4;     // 256 B per wave: where the next round's prefetch DMA lands (never read)
-constexpr int LDS_1P = OFF_PF + 8 * 256;       // 88,576 B: one 8-wave workgroup per CU
-constexpr int PF_DIST = 256;                   // the unit one round of the launch ahead: blocks b and b + 8 k share an XCD (and its
-                                               // L2) under the observed round-robin placement -- a speed assumption only
+constexpr int LDS_1P = OFF_POS + MAXK * 4;     // 86,528 B: one 8-wave workgroup per CU
 static_assert(8 * 8192 <= OFF_LSE, "epilogue staging (8 KiB per wave) overlays the K, slice and dS images only");
 
 #define SNX_ATTN_1P_GROUPS 8
@@ -105,12 +102,7 @@ __device__ unsigned long long* g_attn1p_trace = nullptr;
 
 // NTL ("stream_nt" bit 32): q, k, v and dO are read for the last time here (the attention output O is read again by the
 // layer's weight-gradient GEMM): non-temporal loads keep them from displacing the following GEMMs' operands in the caches.
-// PF ("attn_prefetch"): with one workgroup per CU nothing covers a unit's prologue -- ~90 KB of global loads at ~11 B per
-// cycle and CU when every CU bursts at once: 12.6k of a unit's 54k cycles.  During its LAST slice a workgroup therefore
-// touches, for the unit that block + 256 will compute (same XCD, one round later), one dword of every 128-byte line of that
-// unit's K, V and first Q / dO / O slice: LDS-DMA into a scratch line (no destination register, nothing reads it), which
-// pulls the lines into the XCD's L2 while the HBM pipes are otherwise idle.  Results cannot change.
-template <bool NTL, bool PF>
+template <bool NTL>
 __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, const int32_t* __restrict__ cu_seqlens, const int64_t* __restrict__ mask,
@@ -133,19 +125,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
   if (slen <= 0) return;
   const int H = heads * 64;
   const long rs = 3L * H;
-  // the unit PF_DIST blocks ahead (wave-uniform scalars; its cu_seqlens are requested here, used in the last slice)
-  int pf_len = 0;
-  long pf_row0 = 0;
-  int pf_head = 0;
-  if (PF && (int)blockIdx.x + PF_DIST < (int)gridDim.x) {
-    int g2, u2;
-    block_to_group<SNX_ATTN_1P_GROUPS>(sched.bend, sched.n, sched.interleave, (int)blockIdx.x + PF_DIST, g2, u2);
-    const int seq2 = sched.seq0[g2] + u2 / heads;
-    pf_head = u2 % heads;
-    pf_row0 = cu_seqlens[seq2];
-    const int l2 = cu_seqlens[seq2 + 1] - (int)pf_row0;
-    pf_len = l2 < MAXK ? l2 : MAXK;
-  }
   const bf16_t* qbase = qkv + (long)s0 * rs + head * 64;
   const bf16_t* dobase = dout + (long)s0 * H + head * 64;
   const bf16_t* obase = out + (long)s0 * H + head * 64;
@@ -263,25 +242,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
     }
     WG_BARRIER();
     if (sl < 2) ATRACE(2 + 4 * sl);
-    if (PF && sl == nsl - 1 && pf_len > 0) {                   // workgroup-uniform
-      const int nq = pf_len < QS ? pf_len : QS;
-      const int total = 2 * pf_len + 3 * nq;
-      const bf16_t* q2 = qkv + pf_row0 * rs + pf_head * 64;
-      const unsigned lds_pf = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + OFF_PF + w * 256);
-      for (int i = tid; i < total; i += 512) {
-        const bf16_t* pl;
-        if (i < pf_len) pl = q2 + H + (long)i * rs;                               // K row i
-        else if (i < 2 * pf_len) pl = q2 + 2 * H + (long)(i - pf_len) * rs;       // V row
-        else {
-          const int j = i - 2 * pf_len, which = j / nq, rr2 = j - which * nq;
-          pl = which == 0 ? q2 + (long)rr2 * rs
-                          : (which == 1 ? dout : out) + (pf_row0 + rr2) * H + pf_head * 64;
-        }
-        unsigned m0_keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(m0_keep) : "v"(pl), "s"(lds_pf) : "memory");
-      }
-    }
     if (pend_row) {
       *(bf16x4*)pend_row = pend_lo;
       *(bf16x4*)(pend_row + 32) = pend_hi;
@@ -482,7 +442,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_1p_kernel(
       }
     }
   }
-  if (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
   ATRACE(11); ATRACE_RT(13);
 }
 
@@ -518,11 +477,10 @@ int attn_bwd_onepass(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, c
     sc.bend[i] = (int)b;
   }
   sc.interleave = g_snx_cfg.attn_interleave != 0 && sc.n > 1;
-  static LdsOptIn optin[4];
-  const bool ntl = (g_snx_cfg.stream_nt & 32) != 0, pf = g_snx_cfg.attn_prefetch != 0;
-  auto kern = ntl ? (pf ? attn_bwd_1p_kernel<true, true> : attn_bwd_1p_kernel<true, false>)
-                  : (pf ? attn_bwd_1p_kernel<false, true> : attn_bwd_1p_kernel<false, false>);
-  if (const int rc = optin[(ntl ? 1 : 0) + (pf ? 2 : 0)].ensure((const void*)kern, LDS_1P)) return rc;
+  static LdsOptIn optin[2];
+  const bool ntl = (g_snx_cfg.stream_nt & 32) != 0;
+  auto kern = ntl ? attn_bwd_1p_kernel<true> : attn_bwd_1p_kernel<false>;
+  if (const int rc = optin[ntl ? 1 : 0].ensure((const void*)kern, LDS_1P)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)b), dim3(512), LDS_1P, st, qkv, out, dout, lse, cu_seqlens, mask,
                      dqkv, rope_tab, pos, T, heads, window, 0.125f, sc);
   SNX_CHECK_LAUNCH();

@@ -20,8 +20,6 @@ struct SnxConfig {
   int side_prio = 1;          //   ... which has the lowest stream priority
   int attn_streaming = 0;     // 1: tile-by-tile attention kernels for every sequence length
   int attn_bwd_onepass = 1;   // one-pass attention backward for sequences of <= 256 tokens (0: dQ + dK/dV pair)
-  int attn_prefetch = 0;      // 1: a unit of the one-pass attention backward touches, in its last slice, the lines of the unit that
-                              // block + 256 will compute (L2 prefetch through LDS-DMA; attention_1p.hip)
   int attn_interleave = 0;    // 1: units of the sequence groups interleaved in proportion (attention_common.h); default 0 =
                               // group by group, longest first -- measured level in the step (45.08 against 45.01 ms, ABAB)
   int splade_dh_panels = 64;  // vocabulary panels of the routed decoder backward's dHd gather (0: one wave per row); rounds 3-5: 16,

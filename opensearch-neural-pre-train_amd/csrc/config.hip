@@ -23,7 +23,6 @@ const Key KEYS[] = {
     {"attn_streaming", &SnxConfig::attn_streaming, 0, 1},
     {"attn_bwd_onepass", &SnxConfig::attn_bwd_onepass, 0, 1},
     {"attn_interleave", &SnxConfig::attn_interleave, 0, 1},
-    {"attn_prefetch", &SnxConfig::attn_prefetch, 0, 1},
     {"splade_dh_panels", &SnxConfig::splade_dh_panels, 0, 256},
     {"splade_dw_last", &SnxConfig::splade_dw_last, 0, 2},
     {"f32_gemm64", &SnxConfig::f32_gemm64, 0, 1},

@@ -140,7 +140,7 @@ def _check_build_flags(L):
 ENV_KEYS = {
     "SNX_NT256": "nt256", "SNX_NT256_MIN_M": "nt256_min_m", "SNX_NT256_COLDEAL": "nt256_coldeal", "SNX_NT256_REV": "nt256_rev", "SNX_TN256": "tn256", "SNX_TN256_MIN_M": "tn256_min_m",
     "SNX_DEC256": "dec256", "SNX_DEC256_MIN_T": "dec256_min_t", "SNX_BWD_OVERLAP": "bwd_overlap",
-    "SNX_ATTN_BWD_ONEPASS": "attn_bwd_onepass", "SNX_ATTN_INTERLEAVE": "attn_interleave", "SNX_ATTN_PREFETCH": "attn_prefetch", "SNX_STREAM_NT": "stream_nt", "SNX_SPLADE_DW_LAST": "splade_dw_last", "SNX_SPLADE_DH_PANELS": "splade_dh_panels", "SNX_RESID_IN_LN": "resid_in_ln", "SNX_DET_REDUCE": "det_reduce", "SNX_NT_PIPE": "nt_pipe",
+    "SNX_ATTN_BWD_ONEPASS": "attn_bwd_onepass", "SNX_ATTN_INTERLEAVE": "attn_interleave", "SNX_STREAM_NT": "stream_nt", "SNX_SPLADE_DW_LAST": "splade_dw_last", "SNX_SPLADE_DH_PANELS": "splade_dh_panels", "SNX_RESID_IN_LN": "resid_in_ln", "SNX_DET_REDUCE": "det_reduce", "SNX_NT_PIPE": "nt_pipe",
 }
 
 
