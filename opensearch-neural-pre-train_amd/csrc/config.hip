@@ -23,14 +23,14 @@ const Key KEYS[] = {
     {"attn_streaming", &SnxConfig::attn_streaming, 0, 1},
     {"attn_bwd_onepass", &SnxConfig::attn_bwd_onepass, 0, 1},
     {"attn_interleave", &SnxConfig::attn_interleave, 0, 1},
-    {"splade_dh_panels", &SnxConfig::splade_dh_panels, 0, 256},
+    {"splade_dh_panels", &SnxConfig::splade_dh_panels, 0, 64},
     {"splade_dw_last", &SnxConfig::splade_dw_last, 0, 2},
     {"f32_gemm64", &SnxConfig::f32_gemm64, 0, 1},
     {"f32_attn_rows", &SnxConfig::f32_attn_rows, 0, 1},
     {"wcache_per_tensor", &SnxConfig::wcache_per_tensor, 0, 1},
     {"resid_in_ln", &SnxConfig::resid_in_ln, 0, 1},
     {"det_reduce", &SnxConfig::det_reduce, 0, 1},
-    {"stream_nt", &SnxConfig::stream_nt, 0, 2047},
+    {"stream_nt", &SnxConfig::stream_nt, 0, 511},
     {"nt_pipe", &SnxConfig::nt_pipe, 0, 2},
     {"nt_pipe_min_m", &SnxConfig::nt_pipe_min_m, 1, 1 << 30},
 #ifdef SNX_DIAG

@@ -156,7 +156,7 @@ __device__ __forceinline__ LaneOff lane_offsets(const Tile& t, int wave, int lan
 // AUX: cache-policy bits of the LDS-DMA (0 default, 2 = nt: "stream_nt" bit 16 -- every operand of a weight-gradient GEMM is
 // read for the last time; alone the nt form measured level, 489 vs 482 us per layer group, the question in the step is
 // what its 0.7 GB per launch displace from the caches the launch stream's kernels live on)
-template <int AUX, int AUXB = AUX>
+template <int AUX>
 __device__ __forceinline__ void request_one(const Tile& t, const LaneOff& o, int tok0, char* slot, int wave, int k8) {
   const int k = k8 >> 1;                              // pair index: rows 8 wave + 4 (k >> 1) .., sub-tile k & 1
   char* d = slot + (wave * 8 + (k >> 1) * 4) * 256 + (k & 1) * SUB;
@@ -168,7 +168,7 @@ __device__ __forceinline__ void request_one(const Tile& t, const LaneOff& o, int
   } else {
     const int b2 = ((k & 1) && t.k0 + 128 < t.K) ? 256 : 0;
     const char* bb = (const char*)(t.x + (long)tok0 * t.K) + b2;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(bb + o.b[k >> 1]), LDS_PTR(d + PART), 16, 0, AUXB);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(bb + o.b[k >> 1]), LDS_PTR(d + PART), 16, 0, AUX);
   }
 }
 
@@ -232,9 +232,7 @@ extern "C" int snx_tn256_trace_set(void* buf) {
 
 // SLAB: the flush stores the partial tile into the workspace (ordered reduction); otherwise float atomics into dW.  A
 // template parameter, not a branch: with both flush forms in one kernel hipcc spills 660 bytes per lane.
-// AUX / AUXB: cache policy of the dY / X operand DMA ("stream_nt" bit 16: both nt; 512: X only -- the saved activations, which
-// come from HBM and are read for the last time; 1024: dY only)
-template <bool NODMA, bool SLAB, int AUX = 0, int AUXB = AUX>
+template <bool NODMA, bool SLAB, int AUX = 0>
 __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sched sch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -260,7 +258,7 @@ __global__ __launch_bounds__(256) void gemm_tn256_kernel(TnGroup grp, int M, Sch
   // the MFMA in flight covers 32.
   auto issue = [&](int half, int k8) {
     if (!NODMA)
-      request_one<AUX, AUXB>(ld_tile, ld_off, (sch.dbg & 4) ? 0 : ld_s * 64 + half * HS, smem + ld_slot * SLOT, wave, k8);
+      request_one<AUX>(ld_tile, ld_off, (sch.dbg & 4) ? 0 : ld_s * 64 + half * HS, smem + ld_slot * SLOT, wave, k8);
     if (k8 == 7) ld_slot = ld_slot + 1 == RING ? 0 : ld_slot + 1;
   };
   auto issue_all = [&](int half) {
@@ -526,14 +524,12 @@ int snx_launch_tn256(const TnGroup& g128, int M, void* ws, size_t ws_bytes, hipS
     if (!ws || ws_bytes < (size_t)slabs * s.ntiles * (256 * 256 * 4)) return SNX_E_ARG;
     s.ws = (float*)ws;
   }
-  static LdsOptIn optin[7];
+  static LdsOptIn optin[5];
   void (*kern)(TnGroup, int, Sched);
   int which;
   if (s.ws) { which = (dbg & 2) ? 3 : 2; kern = (dbg & 2) ? gemm_tn256_kernel<true, true> : gemm_tn256_kernel<false, true>; }
   else { which = (dbg & 2) ? 1 : 0; kern = (dbg & 2) ? gemm_tn256_kernel<true, false> : gemm_tn256_kernel<false, false>; }
   if (which == 2 && (g_snx_cfg.stream_nt & 16)) { which = 4; kern = gemm_tn256_kernel<false, true, 2>; }
-  else if (which == 2 && (g_snx_cfg.stream_nt & 512)) { which = 5; kern = gemm_tn256_kernel<false, true, 0, 2>; }
-  else if (which == 2 && (g_snx_cfg.stream_nt & 1024)) { which = 6; kern = gemm_tn256_kernel<false, true, 2, 0>; }
   if (const int rc = optin[which].ensure((const void*)kern, RING * SLOT)) return rc;
   hipLaunchKernelGGL(kern, dim3(NWG), dim3(256), RING * SLOT, st, g, M, s);
   SNX_CHECK_LAUNCH();
