@@ -110,7 +110,10 @@ def cpu_baseline(seconds_budget: float = 30.0, cores: int | None = None):
     timed = times[1:] if len(times) > 1 else times
     return {"value": 4.0 * len(timed) / sum(timed), "unit": "triplets/s", "cores": cores, "host_cores": host, "kind": "port",
             "sample": f"{len(timed)} timed micro-steps (after 1 warm-up) of 4 triplets q64/d256, oracle fp32 incl. "
-                      "clip+AdamW every step"}
+                      "clip+AdamW every step",
+            "cores_note": "16 threads = the host share of one GPU's job on the box; SURVEY 8(d) asks for all physical cores: "
+                          "the same sample on 64 / 128 threads of the shared host measured SLOWER (0.57 / 0.24 triplets/s, "
+                          "profiles/r04_cpu_baseline_cores.json; `bench.py --cpu-baseline-only --cpu-cores all` repeats it)"}
 
 
 # kernel names (as tools/pmc_traffic.py keys them) behind each profiler class, for the PMC traffic lookup
