@@ -29,21 +29,34 @@ def main():
     junk2 = torch.empty_like(junk)
     ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
 
-    def timed(prepare):
-        ts = []
-        for r in range(15):
+    def loop(prepare, with_gemm, n=15):
+        # no event and no host sync between the kernels of a case (a timing event is a system-scope fence: it writes back and
+        # invalidates the L2, so a kernel timed on its own ALWAYS starts on a cold L2): the GEMM's time is the difference
+        # between the loop with it and the loop without it
+        for r in range(4):
             prepare(r)
-            e0, e1 = ev(), ev()
-            e0.record()
-            ops.gemm_nt(a, w)
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(1000.0 * e0.elapsed_time(e1))
-        return statistics.median(ts), min(ts)
+            if with_gemm:
+                ops.gemm_nt(a, w)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for r in range(n):
+            prepare(r)
+            if with_gemm:
+                ops.gemm_nt(a, w)
+        e1.record()
+        torch.cuda.synchronize()
+        return 1000.0 * e0.elapsed_time(e1) / n
+
+    def timed(prepare):
+        with_g = [loop(prepare, True) for _ in range(5)]
+        without = [loop(prepare, False) for _ in range(5)]
+        return statistics.median(with_g) - statistics.median(without), min(with_g) - min(without)
 
     ops.gemm_nt(a, w)
     cases = {
+        "GEMM only, back to back": lambda r: None,
         "warm (A read by the previous GEMM)": lambda r: ops.gemm_nt(a, w),
+        "LayerNorm-sized stream (450 MB copy) in front": lambda r: junk2[:225 * 1024 * 1024].copy_(junk[:225 * 1024 * 1024]),
         "A just written (copy from a rotating source)": lambda r: a.copy_(srcs[r % 4]),
         "A written, then 1 GB streamed": lambda r: (a.copy_(srcs[r % 4]), junk2.copy_(junk)),
         "1 GB streamed (A last read long ago)": lambda r: junk2.copy_(junk),
