@@ -289,9 +289,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossDims d, LossWs w, 
 // gradients of the three inputs; gout = dL/dloss (device scalar)
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ q, const float* __restrict__ p,
                                                        const float* __restrict__ n, const float* __restrict__ gout,
-                                                       LossDims d, LossWs w, int use_kd, int g_in_lds,
-                                                       float* __restrict__ dq, float* __restrict__ dp,
-                                                       float* __restrict__ dn) {
+                                                       LossDims d, LossWs w, int use_kd, float* __restrict__ dq,
+                                                       float* __restrict__ dp, float* __restrict__ dn) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int LD = d.CH + 1;
   float* sq = sm;                       // [B][LD]
@@ -308,16 +307,6 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     const int r = i / d.CH, c = i % d.CH;
     sp[r * LD + c] = c < cw ? p[(long)r * d.V + c0 + c] : 0.f;
   }
-  // The soft-max coefficients G [B, Bp] are wave-uniform operands of the loops below.  Read from memory they come through the
-  // scalar cache, four dependent s_loads per j: the kernel was bound by that latency (134 us at B = Bp = 64 for 77 MB of
-  // traffic).  When they fit beside the tiles (`g_in_lds`: the launcher's decision) they are staged in LDS once per workgroup
-  // and read as broadcasts.  Same values, same order of every sum.
-  const float* Gm = w.G;
-  if (g_in_lds) {
-    float* sG = sm + (d.B + d.Bp) * LD;
-    for (int i = tid; i < d.B * d.Bp; i += 256) sG[i] = w.G[i];
-    Gm = sG;
-  }
   __syncthreads();
   const float fq = 2.f * d.lam_q / (float)d.B, fd = 2.f * d.lam_d / (float)d.B;
   const float fn = 2.f * d.lam_neg / (float)(d.B * d.k);
@@ -332,7 +321,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
       for (int j = 0; j < d.Bp; ++j) {
         const float pv = d.bf16_mm ? rbf(sp[j * LD + c]) : sp[j * LD + c];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s[u] += Gm[(long)min(i0 + u, d.B - 1) * d.Bp + j] * pv;
+        for (int u = 0; u < 4; ++u) s[u] += w.G[(long)min(i0 + u, d.B - 1) * d.Bp + j] * pv;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -360,7 +349,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
       for (int i = 0; i < d.B; ++i) {
         const float qv = d.bf16_mm ? rbf(sq[i * LD + c]) : sq[i * LD + c];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s[u] += Gm[(long)i * d.Bp + min(j0 + u, d.Bp - 1)] * qv;
+        for (int u = 0; u < 4; ++u) s[u] += w.G[(long)i * d.Bp + min(j0 + u, d.Bp - 1)] * qv;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -436,20 +425,9 @@ extern "C" int snx_loss_bwd(const float* q, const float* p, const float* n, cons
   int rc = make_dims(d, dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], hp);
   if (rc) return rc;
   LossWs w = carve((float*)workspace, d.B, d.Bp, d.k, d.V, d.nchunk);
-  // The backward's vocabulary chunk is its own (no output depends on it: every dq / dp / dn element is one sum over rows).  With
-  // the coefficients staged in LDS a 64-column chunk keeps the workgroup at 49 KB (three per CU) where 128 columns + G would
-  // take 82 KB (one per CU).
-  const size_t g_bytes = (size_t)d.B * d.Bp * 4;
-  LossDims db = d;
-  int g_in_lds = 0;
-  if ((size_t)(d.B + d.Bp) * 65 * 4 + g_bytes <= 52 * 1024) {   // (config 4's 512 gathered positives: G stays in memory)
-    g_in_lds = 1;
-    db.CH = d.CH < 64 ? d.CH : 64;
-    db.nchunk = cdiv(d.V, db.CH);
-  }
-  const size_t lds = (size_t)(db.B + db.Bp) * (db.CH + 1) * 4 + (g_in_lds ? g_bytes : 0);
-  hipLaunchKernelGGL(loss_bwd_kernel, dim3(db.nchunk), dim3(256), lds, st, q, p, n, gout, db, w,
-                     (use_kd && d.lam_kd > 0.f) ? 1 : 0, g_in_lds, dq, dp, dn);
+  const size_t lds = (size_t)(d.B + d.Bp) * (d.CH + 1) * 4;
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(d.nchunk), dim3(256), lds, st, q, p, n, gout, d, w,
+                     (use_kd && d.lam_kd > 0.f) ? 1 : 0, dq, dp, dn);
   SNX_CHECK_LAUNCH();
   return SNX_OK;
 }
