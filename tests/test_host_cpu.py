@@ -303,6 +303,13 @@ def _dist_worker(rank, world, port, ret):
         tot = tot + O.cross_rank_infonce(A[r], torch.cat(Ps, 0), N[r], r, 1.5)
     tot.backward()
     ok2 = torch.allclose(p.grad, Ps[rank].grad, atol=1e-6) and pall.shape == (world * B, V)
+    # ... and the exchange-stream form the trainer uses (round 6): on CPU tensors it degrades to the inline collective and
+    # must hand out the same tensor and the same gradient through PendingGather.wait()
+    p2 = P[rank].clone().requires_grad_(True)
+    pend = sd.all_gather_with_grad_async(p2)
+    pall2 = pend.wait()
+    O.cross_rank_infonce(A[rank], pall2, N[rank], rank, 1.5).backward()
+    ok2 = ok2 and torch.equal(pall2.detach(), pall.detach()) and torch.equal(p2.grad, p.grad) and pend.wait() is pall2
     from src.train.core import ddp_trainer as T
     ok3 = T.is_main_process() == (rank == 0)
     # (3) the bucketed exchange that overlaps the backward: drive BucketedGradSync exactly as
